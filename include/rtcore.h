@@ -1,0 +1,248 @@
+/* rtcore.h -- C ABI of librtcore.so, the MI355X (gfx950) path-tracing core.
+ *
+ * The reference project drives its GPU path only through Unity's
+ * ComputeShader / ComputeBuffer / Graphics.Blit objects; it has no native
+ * plugin seam.  Each entry point below replaces one group of those calls and
+ * cites the reference call site it stands in for.  A C# host binds them with
+ * [DllImport("rtcore")]; every struct here is blittable and has the byte
+ * layout of the reference's own GPU structs.
+ *
+ * Conventions
+ *   - every call returns 0 (RT_OK) or a negative RT_E_* code; nothing throws
+ *     or aborts across the boundary; rt_last_error() gives the message.
+ *   - the caller owns every host array; the library copies during the call.
+ *   - the library owns all device memory behind the opaque RtContext.
+ *   - one RtContext = one GPU = one caller thread at a time.
+ *   - 4x4 matrices are 16 floats in Unity Matrix4x4 memory order
+ *     (column-major: element(row r, col c) = m[c*4 + r]).
+ *   - image row 0 is the bottom of the view (RayTracing.compute:58).
+ */
+#ifndef RTCORE_H_
+#define RTCORE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------ error codes */
+#define RT_OK 0
+#define RT_E_INVALID   (-1)  /* bad argument / call order */
+#define RT_E_DEVICE    (-2)  /* HIP runtime error (no GPU, launch failure, ...) */
+#define RT_E_NOMEM     (-3)
+#define RT_E_STATE     (-4)  /* e.g. dispatch before rt_bvh_build */
+#define RT_E_OVERFLOW  (-5)  /* traversal stack overflow flagged by a kernel */
+
+/* ------------------------------------------------- wire structs (blittable) */
+/* Assets/Shaders/BVH/Constants.cginc:11-17, Assets/Scripts/BVH/SceneDataTypes.cs:6-21 */
+typedef struct RtAABB {
+    float min[3]; float _dummy0;
+    float max[3]; float _dummy1;
+} RtAABB;                                   /* 32 B */
+
+/* Constants.cginc:20-59, SceneDataTypes.cs:23-86 */
+typedef struct RtTriangle {
+    float point0[3]; float _dummy0;
+    float point1[3]; float _dummy1;
+    float point2[3]; float _dummy2;
+    float uv0[2]; float uv1[2]; float uv2[2]; float _dummy3[2];
+    float normal0[3]; float _dummy4;
+    float normal1[3]; float _dummy5;
+    float normal2[3]; float _dummy6;
+    float tangent0[3]; float _dummy7;
+    float tangent1[3]; float _dummy8;
+    float tangent2[3]; float _dummy9;
+    int32_t materialIndex; int32_t castShadow; int32_t receiveShadow; float _dummy10;
+} RtTriangle;                               /* 192 B */
+
+/* Constants.cginc:62-79, SceneDataTypes.cs:88-120 */
+#define RT_INTERNAL_NODE 0u
+#define RT_LEAF_NODE 1u
+typedef struct RtInternalNode {
+    uint32_t leftNode, leftNodeType, rightNode, rightNodeType, parent, index;
+} RtInternalNode;                           /* 24 B */
+typedef struct RtLeafNode { uint32_t parent, index; } RtLeafNode; /* 8 B */
+
+/* Assets/Shaders/BVH/BVHRayTracing.cginc:6-17, Assets/Scripts/BVH/BVH.cs:24-37 */
+typedef struct RtMaterialData {
+    float albedo[3];
+    float metallic;
+    float smoothness;
+    float transparent;
+    float emissionColor[3];
+    uint32_t materialType;  /* 0 opaque, 1 transparent, 2 emission, 3 clear coat, 4 matte mask */
+    float ior;
+    float clearCoatColor[3];
+} RtMaterialData;                           /* 56 B */
+
+/* BVH.cs:15-21; MeshData.compute:27-38 (11 floats per vertex) */
+typedef struct RtMeshVertex {
+    float position[3]; float normal[3]; float tangent[3]; float uv[2];
+} RtMeshVertex;                             /* 44 B */
+
+/* ImportanceSampling.cginc:8-39, LightImportanceSampling.cs:16-55 */
+typedef struct RtSphereLight { float position[3]; float radius; } RtSphereLight;      /* 16 B */
+typedef struct RtAreaLight { float position[3]; float normal[3]; float up[3]; float size[2]; } RtAreaLight; /* 44 B */
+typedef struct RtDiscLight { float position[3]; float normal[3]; float radius; } RtDiscLight; /* 28 B */
+
+/* ------------------------------------------------------------------ flags */
+/* RayTracing.cs:40-48 (SamplingType) -> bits 0..2 */
+#define RT_SAMPLING_UNIFORM   0u
+#define RT_SAMPLING_COSINE    1u
+#define RT_SAMPLING_LIGHT     2u
+#define RT_SAMPLING_BSDF      3u
+#define RT_SAMPLING_MIS       4u
+#define RT_FLAG_SAMPLING_MASK 0x7u
+/* DepthOfField.cs:22-36: DEPTH_OF_FIELD keyword.  In the reference only the
+ * ShadowMap kernel honours it (RayTracing.compute:60-65 vs 105-110). */
+#define RT_FLAG_DEPTH_OF_FIELD   0x10u
+/* Extension, off by default: also use the DoF camera for CSMain primary rays. */
+#define RT_FLAG_DOF_PRIMARY      0x20u
+/* RayTracing.cs:178-182: a matte-mask object exists -> ShadowMap pass runs. */
+#define RT_FLAG_MATTE_MASK       0x40u
+
+/* POD mirror of every uniform the reference sets on RayTracing.compute:
+ * RayTracing.cs:194-204,223-230,256-260; DepthOfField.cs:22-36. */
+typedef struct RtParams {
+    int32_t width, height;
+    float camera2World[16];
+    float cameraInverseProjection[16];
+    float seed;                 /* per-frame: RayTracing.cs:230 */
+    float lightParameter[4];    /* xyz = mainLight forward, w = lightRadius */
+    float lightColor[4];        /* rgb = light colour, a = skyboxIntensityMulitiply */
+    float shadowParameter[4];   /* rgb = shadow colour, a = shadowIntensity */
+    float skyboxRotation;
+    float skyboxExposure;
+    float lensRadius;
+    float focalLength;
+    uint32_t flags;
+    /* Image-tile sharding (no counterpart in the reference; single GPU there).
+     * The frame is cut into tileSize x tileSize tiles in row-major order and
+     * this context renders tiles t with t % tileCount == tileRank.  Pixel
+     * coordinates given to the RNG stay global, so the union of all ranks'
+     * tiles is bit-identical to a single-GPU frame.  tileCount <= 1 = whole frame. */
+    int32_t tileRank, tileCount, tileSize;
+} RtParams;
+
+typedef struct RtContext RtContext;
+
+/* Work counters of the BVH traversal since the last rt_reset_stats. */
+typedef struct RtStats {
+    uint64_t rays;            /* BVHRayTrace calls */
+    uint64_t internalVisits;  /* internal-node boxes tested (n_I)  */
+    uint64_t leafVisits;      /* leaf triangle boxes tested (n_L)  */
+    uint64_t triTests;        /* triangles that passed their box (n_T) */
+    uint64_t hits;            /* rays that ended with a hit (h) */
+    uint64_t paths;           /* camera paths generated */
+    double buildMs;           /* device time of the last rt_bvh_build */
+    double renderMs;          /* device time of the last dispatch / render_frames */
+} RtStats;
+
+/* ---------------------------------------------------------------- lifetime */
+/* Replaces ComputeShader/ComputeBuffer object creation in RayTracing.Start
+ * (RayTracing.cs:68-97).  device_id is the HIP device ordinal. */
+int rt_create(int device_id, RtContext **out_ctx);
+/* RayTracing.cs:319-334, BVH.cs:554-559, MeshBufferContainer.cs:115-129. Idempotent on NULL. */
+int rt_destroy(RtContext *ctx);
+const char *rt_last_error(RtContext *ctx);
+
+/* ------------------------------------------------------------ scene upload */
+/* The merged world-space mesh that BVH.InitMesh builds (BVH.cs:201-318) and
+ * MeshBufferContainer uploads (MeshBufferContainer.cs:78-89): vertex buffer,
+ * uint32 index buffer, per-triangle material index, per-triangle (cast,receive). */
+int rt_scene_upload(RtContext *ctx, const RtMeshVertex *vertices, uint32_t n_vertices,
+                    const uint32_t *indices, uint32_t n_indices,
+                    const uint32_t *material_index, const int32_t *shadow_index_xy,
+                    uint32_t n_triangles);
+/* BVH.InitMaterialData / UpdateMaterialData (BVH.cs:320-325,334-352).  Also marks dirty. */
+int rt_materials_upload(RtContext *ctx, const RtMaterialData *materials, uint32_t n);
+/* LightImportanceSampling.Init (LightImportanceSampling.cs:57-107): a count of
+ * zero disables the corresponding SPHERE_/AREA_/DISC_LIGHT keyword. */
+int rt_lights_upload(RtContext *ctx, const RtSphereLight *sphere, uint32_t n_sphere,
+                     const RtAreaLight *area, uint32_t n_area,
+                     const RtDiscLight *disc, uint32_t n_disc);
+/* cs.SetTexture(kernel,"skyboxCube",...) (RayTracing.cs:198-205).  faces = 6
+ * images of size x size RGBA float32 in D3D face order +X,-X,+Y,-Y,+Z,-Z,
+ * each row-major with v downwards.  size = 0 unbinds (samples read 0). */
+int rt_skybox_upload(RtContext *ctx, const float *faces_rgba, uint32_t size);
+
+/* --------------------------------------------------------------- BVH build */
+/* MeshData.Calculate + ComputeBufferSorter.Sort + DistributeMortonCode +
+ * BVHConstructor.ConstructTree/ConstructBVH (BVH.cs:128-170). */
+int rt_bvh_build(RtContext *ctx);
+
+/* Debug readbacks in the reference wire structs, what BVH.OnDrawGizmos reads
+ * (BVH.cs:361-367,501-505).  Any pointer may be NULL.  Array lengths:
+ * morton/sorted_index/tri_aabb/triangles/leaf_nodes: N; internal_nodes/bvh_data: N-1. */
+int rt_readback_bvh(RtContext *ctx, uint32_t *morton_codes, uint32_t *sorted_triangle_index,
+                    RtAABB *triangle_aabb, RtTriangle *triangles,
+                    RtInternalNode *internal_nodes, RtLeafNode *leaf_nodes, RtAABB *bvh_data);
+/* Intermediate build products for the sorter's own checks
+ * (ComputeBufferSorter.cs:155-182): Morton codes before sorting and the sorted
+ * codes before DistributeMortonCode.  Either may be NULL. */
+int rt_readback_sort_stages(RtContext *ctx, uint32_t *morton_unsorted, uint32_t *morton_sorted_raw);
+
+/* ------------------------------------------------------------------ render */
+/* Every cs.Set* of RayTracing.InitShader/InitLight/InitSampling/UpdateParameters. */
+int rt_set_params(RtContext *ctx, const RtParams *params);
+/* cs.Dispatch(kernelHandle, ...) = CSMain, one sample per pixel into `rt`
+ * (RayTracing.cs:128-132). */
+int rt_dispatch(RtContext *ctx);
+/* cs.Dispatch(kernelHandleShadowMap, ...) (RayTracing.cs:134-135). */
+int rt_dispatch_shadowmap(RtContext *ctx);
+/* Graphics.Blit(rt, convergedRT, addMaterial, pass) with _SamplePrePixel
+ * (RayTracing.cs:138-150, AddShader.shader:12,47-79). */
+int rt_accumulate(RtContext *ctx, uint32_t sample_per_pixel, int use_shadow_map);
+/* n_frames x { seed := seeds[k]; CSMain; [ShadowMap]; accumulate; samplePrePixel++ }
+ * without returning to the host in between = n_frames calls of CustomRender
+ * (RayTracing.cs:118-164).  Starts from the context's own sample counter. */
+int rt_render_frames(RtContext *ctx, const float *seeds, uint32_t n_frames);
+/* RayTracing.SetDirty (RayTracing.cs:314-317). */
+int rt_set_dirty(RtContext *ctx);
+uint32_t rt_sample_count(RtContext *ctx);
+
+#define RT_IMAGE_RT        0   /* last 1-spp frame  (RayTracing.rt) */
+#define RT_IMAGE_CONVERGED 1   /* running mean      (RayTracing.convergedRT) */
+#define RT_IMAGE_SHADOWMAP 2   /* RayTracing.shadowMap */
+/* Full-frame float4 readback (width*height*4 floats, row 0 = bottom).  Pixels
+ * of tiles owned by other ranks read 0. */
+int rt_readback(RtContext *ctx, int which, float *dst_rgba);
+/* Same image, but only this rank's tiles in tile-local order, copied to a
+ * DEVICE pointer (e.g. a torch tensor) of rt_local_pixel_count()*4 floats, for
+ * gathering over RCCL without a host hop. */
+int rt_readback_local_device(RtContext *ctx, int which, void *device_dst);
+/* Resume support: load a running mean + its sample count (checkpoint of
+ * RayTracing.convergedRT + samplePrePixel, RayTracing.cs:31-33). */
+int rt_upload_converged(RtContext *ctx, const float *src_rgba, uint32_t sample_per_pixel);
+uint32_t rt_local_pixel_count(RtContext *ctx);
+/* Global pixel index (y*width+x, or 0xFFFFFFFF for padding slots) of every
+ * tile-local slot, so a gatherer can place each rank's pixels. */
+int rt_local_pixel_map(RtContext *ctx, uint32_t *dst);
+
+/* First-hit queries = BVHRayTrace (BVHRayTracing.cginc:125-133) for a batch of
+ * caller rays: origins/directions are n x 3 floats; outputs (any may be NULL)
+ * are distance (inf on miss), original triangle index (0xFFFFFFFF on miss) and
+ * barycentric u,v.  Used for parity checks and the traversal stress test. */
+int rt_trace_rays(RtContext *ctx, const float *origins, const float *directions, uint32_t n,
+                  float *out_t, uint32_t *out_triangle, float *out_u, float *out_v);
+/* Same query on rays already resident in device memory (n x float4 each,
+ * xyz used); hit records (t,u,v,tri-as-bits) are written to device_hits. */
+int rt_trace_rays_device(RtContext *ctx, const void *device_origins4, const void *device_dirs4,
+                         uint32_t n, void *device_hits4);
+
+/* ------------------------------------------------------------------- stats */
+/* When enabled, traversal kernels count node/leaf/triangle tests (slower). */
+int rt_enable_counters(RtContext *ctx, int enable);
+int rt_reset_stats(RtContext *ctx);
+int rt_get_stats(RtContext *ctx, RtStats *out);
+/* Name and mean device time (ms) of the dominant kernel since the last
+ * rt_reset_stats, measured with HIP events on the library's own stream. */
+int rt_kernel_time(RtContext *ctx, const char *kernel_name, double *out_total_ms, uint64_t *out_launches);
+int rt_synchronize(RtContext *ctx);
+const char *rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTCORE_H_ */

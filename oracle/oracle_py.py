@@ -1,0 +1,176 @@
+"""ctypes binding of the CPU checker (oracle/librt_oracle.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the raytracing_amd package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from raytracing_amd import wire
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "librt_oracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "librt_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.orc_scene_create.restype = C.c_void_p
+        _LIB.orc_morton_code.restype = C.c_uint32
+        _LIB.orc_morton_code.argtypes = [C.c_float] * 3
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    def __init__(self, scene):
+        L = lib()
+        self.scene = scene
+        self.n = scene.n_triangles
+        v = np.ascontiguousarray(scene.vertices)
+        i = np.ascontiguousarray(scene.indices, np.uint32)
+        mi = np.ascontiguousarray(scene.material_index, np.uint32)
+        sh = np.ascontiguousarray(scene.shadow_index, np.int32)
+        self.h = C.c_void_p(L.orc_scene_create(_p(v), C.c_uint32(len(v)), _p(i), C.c_uint32(len(i)), _p(mi), _p(sh),
+                                               C.c_uint32(self.n)))
+        m = np.ascontiguousarray(scene.materials)
+        L.orc_set_materials(self.h, _p(m), C.c_uint32(len(m)))
+        sl, al, dl = (np.ascontiguousarray(x) for x in (scene.sphere_lights, scene.area_lights, scene.disc_lights))
+        L.orc_set_lights(self.h, _p(sl), C.c_uint32(len(sl)), _p(al), C.c_uint32(len(al)), _p(dl), C.c_uint32(len(dl)))
+        if scene.skybox is not None:
+            sk = np.ascontiguousarray(scene.skybox, np.float32)
+            L.orc_set_skybox(self.h, _p(sk), C.c_uint32(sk.shape[1]))
+        self.built = False
+
+    def __del__(self):
+        try:
+            lib().orc_scene_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_materials(self, materials):
+        m = np.ascontiguousarray(materials)
+        lib().orc_set_materials(self.h, _p(m), C.c_uint32(len(m)))
+
+    def build(self):
+        lib().orc_build(self.h)
+        self.built = True
+        return self
+
+    def readback_bvh(self):
+        n = self.n
+        out = dict(morton=np.zeros(n, np.uint32), sorted_index=np.zeros(n, np.uint32),
+                   tri_aabb=np.zeros(n, wire.AABB), triangles=np.zeros(n, wire.TRIANGLE),
+                   internal=np.zeros(max(n - 1, 0), wire.INTERNAL_NODE), leaves=np.zeros(n, wire.LEAF_NODE),
+                   bvh_data=np.zeros(max(n - 1, 0), wire.AABB))
+        lib().orc_readback_bvh(self.h, _p(out["morton"]), _p(out["sorted_index"]), _p(out["tri_aabb"]),
+                               _p(out["triangles"]), _p(out["internal"]), _p(out["leaves"]), _p(out["bvh_data"]))
+        un, raw = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        lib().orc_readback_sort_stages(self.h, _p(un), _p(raw))
+        out["morton_unsorted"], out["morton_sorted_raw"] = un, raw
+        return out
+
+    def trace(self, origins, directions, brute=False):
+        o = np.ascontiguousarray(origins, np.float32)
+        d = np.ascontiguousarray(directions, np.float32)
+        n = len(o)
+        t, tri = np.zeros(n, np.float32), np.zeros(n, np.uint32)
+        if brute:
+            lib().orc_trace_brute(self.h, _p(o), _p(d), C.c_uint32(n), _p(t), _p(tri))
+            return dict(t=t, triangle=tri)
+        u, v, cnt = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(5, np.uint64)
+        lib().orc_trace(self.h, _p(o), _p(d), C.c_uint32(n), _p(t), _p(tri), _p(u), _p(v), _p(cnt))
+        return dict(t=t, triangle=tri, u=u, v=v,
+                    counters=dict(zip(("rays", "internalVisits", "leafVisits", "triTests", "hits"), map(int, cnt))))
+
+    def render(self, params, counters=False):
+        img = np.zeros((params.height, params.width, 4), np.float32)
+        cnt = np.zeros(5, np.uint64)
+        lib().orc_render(self.h, C.byref(params), _p(img), _p(cnt))
+        if counters:
+            return img, dict(zip(("rays", "internalVisits", "leafVisits", "triTests", "hits"), map(int, cnt)))
+        return img
+
+    def shadowmap(self, params):
+        img = np.zeros((params.height, params.width, 4), np.float32)
+        lib().orc_shadowmap(self.h, C.byref(params), _p(img))
+        return img
+
+
+def accumulate(converged, rt, shadow_map, sample_per_pixel, use_shadow):
+    sm = rt if shadow_map is None else np.ascontiguousarray(shadow_map, np.float32)
+    rt = np.ascontiguousarray(rt, np.float32)
+    lib().orc_accumulate(_p(converged), _p(rt), _p(sm), C.c_uint32(sample_per_pixel),
+                         C.c_uint64(converged.size // 4), C.c_int(1 if use_shadow else 0))
+    return converged
+
+
+def render_frames(oracle, params, seeds, use_shadow=False):
+    """n x CustomRender (RayTracing.cs:118-164): returns the running mean."""
+    conv = np.zeros((params.height, params.width, 4), np.float32)
+    p = params.copy()
+    for k, s in enumerate(seeds):
+        p.seed = float(s)
+        rt = oracle.render(p)
+        sm = oracle.shadowmap(p) if use_shadow else None
+        accumulate(conv, rt, sm, k, use_shadow)
+    return conv
+
+
+def rand_sequence(px, py, seed, n):
+    out, st = np.zeros(n, np.float32), np.zeros(n, np.uint32)
+    lib().orc_rand_sequence(C.c_uint32(px), C.c_uint32(py), C.c_float(seed), C.c_uint32(n), _p(out), _p(st))
+    return out, st
+
+
+def math(which, x, y=None):
+    x = np.ascontiguousarray(x, np.float32)
+    y = x if y is None else np.ascontiguousarray(y, np.float32)
+    out = np.zeros_like(x)
+    lib().orc_math(C.c_int(which), _p(x), _p(y), C.c_uint32(x.size), _p(out))
+    return out
+
+
+def radix_sort(keys, vals):
+    k, v = np.array(keys, np.uint32), np.array(vals, np.uint32)
+    lib().orc_radix_sort(_p(k), _p(v), C.c_uint32(len(k)))
+    return k, v
+
+
+def distribute_morton(keys):
+    k = np.array(keys, np.uint32)
+    lib().orc_distribute_morton(_p(k), C.c_uint32(len(k)))
+    return k
+
+
+def tree_from_codes(codes):
+    c = np.ascontiguousarray(codes, np.uint32)
+    n = len(c)
+    inodes, leaves = np.zeros(max(n - 1, 0), wire.INTERNAL_NODE), np.zeros(n, wire.LEAF_NODE)
+    lib().orc_tree_from_codes(_p(c), C.c_uint32(n), _p(inodes), _p(leaves))
+    return inodes, leaves
+
+
+def morton_code(x, y, z):
+    return int(lib().orc_morton_code(x, y, z))
+
+
+def brdf_table(params, material, dirs9):
+    d = np.ascontiguousarray(dirs9, np.float32)
+    out = np.zeros((len(d), 4), np.float32)
+    m = np.ascontiguousarray(material)
+    lib().orc_brdf_table(C.byref(params), _p(m), _p(d), C.c_uint32(len(d)), _p(out))
+    return out
