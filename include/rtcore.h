@@ -231,9 +231,18 @@ int rt_trace_rays(RtContext *ctx, const float *origins, const float *directions,
 int rt_trace_rays_device(RtContext *ctx, const void *device_origins4, const void *device_dirs4,
                          uint32_t n, void *device_hits4);
 
+/* Numeric self-check: evaluates one of the shared numeric rules of rt_math.h on
+ * the device for n host inputs (which: 0 sin, 1 cos, 2 acos, 3 pow(x,y),
+ * 4 sRGB->linear, 5 linear->sRGB, 6 float->uint as bits, 7 the Rand() stream of
+ * pixel (x[0],x[1]) with seed y[0], Header.cginc:79-92).  No reference counterpart. */
+int rt_debug_eval(RtContext *ctx, int which, const float *x, const float *y, uint32_t n, float *out);
+
 /* ------------------------------------------------------------------- stats */
 /* When enabled, traversal kernels count node/leaf/triangle tests (slower). */
 int rt_enable_counters(RtContext *ctx, int enable);
+/* When enabled, every kernel launch is bracketed by HIP events on the library's
+ * stream; rt_kernel_time reports per-kernel totals. */
+int rt_enable_kernel_timing(RtContext *ctx, int enable);
 int rt_reset_stats(RtContext *ctx);
 int rt_get_stats(RtContext *ctx, RtStats *out);
 /* Name and mean device time (ms) of the dominant kernel since the last

@@ -1,0 +1,552 @@
+// api.hip -- the extern "C" surface of librtcore.so (include/rtcore.h).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <new>
+
+#include "rt_internal.h"
+
+int rt_fail(RtContext *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+// ---- per-kernel device timing with HIP events on the library's stream --------
+static hipEvent_t take_event(RtContext *ctx)
+{
+    if (!ctx->eventPool.empty()) {
+        hipEvent_t e = ctx->eventPool.back();
+        ctx->eventPool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void rt_timer_begin(RtContext *ctx, const char *name)
+{
+    if (!ctx->timingOn) return;
+    RtPendingEvent p;
+    p.name = name;
+    p.start = take_event(ctx);
+    p.stop = take_event(ctx);
+    (void)hipEventRecord(p.start, ctx->stream);
+    ctx->pending.push_back(p);
+}
+
+void rt_timer_end(RtContext *ctx)
+{
+    if (!ctx->timingOn || ctx->pending.empty()) return;
+    (void)hipEventRecord(ctx->pending.back().stop, ctx->stream);
+}
+
+void rt_timer_resolve(RtContext *ctx)
+{
+    if (ctx->pending.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (RtPendingEvent &p : ctx->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+            RtKernelTimer &t = ctx->timers[p.name];
+            t.totalMs += ms;
+            t.launches += 1;
+        }
+        ctx->eventPool.push_back(p.start);
+        ctx->eventPool.push_back(p.stop);
+    }
+    ctx->pending.clear();
+}
+
+static int use_device(RtContext *ctx)
+{
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    return RT_OK;
+}
+
+#define RT_ENTER(ctx)                                   \
+    if (!(ctx)) return RT_E_INVALID;                    \
+    {                                                   \
+        int rc__ = use_device(ctx);                     \
+        if (rc__) return rc__;                          \
+    }
+
+template <typename T>
+static int upload(RtContext *ctx, T **dst, const T *src, size_t count)
+{
+    if (*dst) {
+        (void)hipFree(*dst);
+        *dst = nullptr;
+    }
+    RT_HIP(ctx, hipMalloc((void **)dst, (count ? count : 1) * sizeof(T)));
+    if (count) RT_HIP(ctx, hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+static int check_error_flag(RtContext *ctx)
+{
+    uint32_t flag = 0;
+    RT_HIP(ctx, hipMemcpy(&flag, ctx->dErrorFlag, 4, hipMemcpyDeviceToHost));
+    if (flag) {
+        (void)hipMemset(ctx->dErrorFlag, 0, 4);
+        return rt_fail(ctx, RT_E_OVERFLOW, "traversal stack overflow (depth > %d)", RT_STACK_DEPTH);
+    }
+    return RT_OK;
+}
+
+extern "C" {
+
+const char *rt_version(void) { return "rtcore 0.1 (gfx950)"; }
+
+int rt_create(int device_id, RtContext **out_ctx)
+{
+    if (!out_ctx) return RT_E_INVALID;
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RT_E_DEVICE;
+    if (device_id < 0 || device_id >= n) return RT_E_INVALID;
+    RtContext *ctx = new (std::nothrow) RtContext();
+    if (!ctx) return RT_E_NOMEM;
+    ctx->device = device_id;
+    memset(&ctx->params, 0, sizeof ctx->params);
+    memset(&ctx->tile, 0, sizeof ctx->tile);
+    memset(&ctx->rootBox, 0, sizeof ctx->rootBox);
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **)&ctx->dStats, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void **)&ctx->dErrorFlag, 4) != hipSuccess) {
+        delete ctx;
+        return RT_E_DEVICE;
+    }
+    (void)hipMemset(ctx->dStats, 0, 8 * sizeof(unsigned long long));
+    (void)hipMemset(ctx->dErrorFlag, 0, 4);
+    *out_ctx = ctx;
+    return RT_OK;
+}
+
+int rt_destroy(RtContext *ctx)
+{
+    if (!ctx) return RT_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    rt_timer_resolve(ctx);
+    for (hipEvent_t e : ctx->eventPool) (void)hipEventDestroy(e);
+    rt_free_build(ctx);
+    rt_free_render(ctx);
+    void *ptrs[] = {ctx->dVerts, ctx->dIdx, ctx->dMatIdx, ctx->dShadow, ctx->dMats, ctx->dSphere, ctx->dArea,
+                    ctx->dDisc, ctx->dCube, ctx->dStats, ctx->dErrorFlag};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RT_OK;
+}
+
+const char *rt_last_error(RtContext *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int rt_scene_upload(RtContext *ctx, const RtMeshVertex *vertices, uint32_t n_vertices, const uint32_t *indices,
+                    uint32_t n_indices, const uint32_t *material_index, const int32_t *shadow_index_xy, uint32_t n_triangles)
+{
+    RT_ENTER(ctx);
+    if (n_indices != 3ull * n_triangles) return rt_fail(ctx, RT_E_INVALID, "n_indices (%u) != 3 * n_triangles (%u)", n_indices, n_triangles);
+    if (n_triangles && (!vertices || !indices || !material_index || !shadow_index_xy))
+        return rt_fail(ctx, RT_E_INVALID, "null scene array");
+    if (n_triangles >= 0x7FFFFFFFu) return rt_fail(ctx, RT_E_INVALID, "too many triangles");
+    for (uint32_t i = 0; i < n_indices; ++i)   // every index a kernel dereferences is checked here
+        if (indices[i] >= n_vertices) return rt_fail(ctx, RT_E_INVALID, "index %u out of range at %u", indices[i], i);
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc;
+    if ((rc = upload(ctx, &ctx->dVerts, vertices, n_vertices))) return rc;
+    if ((rc = upload(ctx, &ctx->dIdx, indices, n_indices))) return rc;
+    if ((rc = upload(ctx, &ctx->dMatIdx, material_index, n_triangles))) return rc;
+    if ((rc = upload(ctx, &ctx->dShadow, shadow_index_xy, 2 * (size_t)n_triangles))) return rc;
+    ctx->nVerts = n_vertices;
+    ctx->N = n_triangles;
+    rt_free_build(ctx);
+    ctx->sampleCount = 0;
+    return RT_OK;
+}
+
+int rt_materials_upload(RtContext *ctx, const RtMaterialData *materials, uint32_t n)
+{
+    RT_ENTER(ctx);
+    if (n && !materials) return rt_fail(ctx, RT_E_INVALID, "null materials");
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc;
+    if ((rc = upload(ctx, &ctx->dMats, materials, n))) return rc;
+    ctx->nMats = n;
+    ctx->sampleCount = 0;   // BVH.UpdateMaterialData ends with RayTracing.SetDirty()
+    return RT_OK;
+}
+
+int rt_lights_upload(RtContext *ctx, const RtSphereLight *sphere, uint32_t n_sphere, const RtAreaLight *area, uint32_t n_area,
+                     const RtDiscLight *disc, uint32_t n_disc)
+{
+    RT_ENTER(ctx);
+    if ((n_sphere && !sphere) || (n_area && !area) || (n_disc && !disc)) return rt_fail(ctx, RT_E_INVALID, "null light array");
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc;
+    if ((rc = upload(ctx, &ctx->dSphere, sphere, n_sphere))) return rc;
+    if ((rc = upload(ctx, &ctx->dArea, area, n_area))) return rc;
+    if ((rc = upload(ctx, &ctx->dDisc, disc, n_disc))) return rc;
+    ctx->nSphere = n_sphere;
+    ctx->nArea = n_area;
+    ctx->nDisc = n_disc;
+    return RT_OK;
+}
+
+int rt_skybox_upload(RtContext *ctx, const float *faces_rgba, uint32_t size)
+{
+    RT_ENTER(ctx);
+    if (size && !faces_rgba) return rt_fail(ctx, RT_E_INVALID, "null skybox");
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc;
+    if ((rc = upload(ctx, &ctx->dCube, (const float4 *)faces_rgba, (size_t)6 * size * size))) return rc;
+    ctx->cubeSize = size;
+    return RT_OK;
+}
+
+int rt_bvh_build(RtContext *ctx)
+{
+    RT_ENTER(ctx);
+    if (ctx->N && !ctx->dVerts) return rt_fail(ctx, RT_E_STATE, "rt_bvh_build before rt_scene_upload");
+    const int rc = rt_build_impl(ctx);
+    rt_timer_resolve(ctx);
+    return rc;
+}
+
+int rt_readback_bvh(RtContext *ctx, uint32_t *morton_codes, uint32_t *sorted_triangle_index, RtAABB *triangle_aabb,
+                    RtTriangle *triangles, RtInternalNode *internal_nodes, RtLeafNode *leaf_nodes, RtAABB *bvh_data)
+{
+    RT_ENTER(ctx);
+    if (!ctx->built) return rt_fail(ctx, RT_E_STATE, "rt_readback_bvh before rt_bvh_build");
+    return rt_readback_bvh_impl(ctx, morton_codes, sorted_triangle_index, triangle_aabb, triangles, internal_nodes, leaf_nodes,
+                                bvh_data);
+}
+
+int rt_readback_sort_stages(RtContext *ctx, uint32_t *morton_unsorted, uint32_t *morton_sorted_raw)
+{
+    RT_ENTER(ctx);
+    if (!ctx->built) return rt_fail(ctx, RT_E_STATE, "rt_readback_sort_stages before rt_bvh_build");
+    if (ctx->N == 0) return RT_OK;
+    if (morton_unsorted) RT_HIP(ctx, hipMemcpy(morton_unsorted, ctx->dMortonUnsorted, (size_t)ctx->N * 4, hipMemcpyDeviceToHost));
+    if (morton_sorted_raw) RT_HIP(ctx, hipMemcpy(morton_sorted_raw, ctx->dMortonSortedRaw, (size_t)ctx->N * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_set_params(RtContext *ctx, const RtParams *p)
+{
+    RT_ENTER(ctx);
+    if (!p) return rt_fail(ctx, RT_E_INVALID, "null params");
+    if (p->width <= 0 || p->height <= 0 || p->width > 32768 || p->height > 32768)
+        return rt_fail(ctx, RT_E_INVALID, "bad image size %d x %d", p->width, p->height);
+    RtParams q = *p;
+    if (q.tileCount <= 1) { q.tileCount = 1; q.tileRank = 0; }
+    if (q.tileSize <= 0) q.tileSize = 64;
+    if (q.tileSize % 8 != 0 || q.tileSize > 1024) return rt_fail(ctx, RT_E_INVALID, "tileSize must be a multiple of 8, <= 1024");
+    if (q.tileRank < 0 || q.tileRank >= q.tileCount) return rt_fail(ctx, RT_E_INVALID, "tileRank %d outside [0,%d)", q.tileRank, q.tileCount);
+    RtTileMap tm;
+    tm.width = q.width;
+    tm.height = q.height;
+    tm.tileSize = q.tileSize;
+    tm.tilesX = (q.width + q.tileSize - 1) / q.tileSize;
+    tm.tilesY = (q.height + q.tileSize - 1) / q.tileSize;
+    tm.rank = q.tileRank;
+    tm.count = q.tileCount;
+    const uint32_t T = (uint32_t)tm.tilesX * (uint32_t)tm.tilesY;
+    tm.nLocalTiles = T > (uint32_t)q.tileRank ? (T - (uint32_t)q.tileRank + (uint32_t)q.tileCount - 1) / (uint32_t)q.tileCount : 0;
+    tm.nSlots = tm.nLocalTiles * (uint32_t)(q.tileSize * q.tileSize);
+    const bool geometryChanged = !ctx->paramsSet || memcmp(&tm, &ctx->tile, sizeof tm) != 0;
+    ctx->params = q;
+    ctx->tile = tm;
+    ctx->paramsSet = true;
+    if (geometryChanged) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return rt_alloc_render(ctx);   // new render targets: InitRT resets samplePrePixel (RayTracing.cs:172-187)
+    }
+    return RT_OK;
+}
+
+static int ready_to_render(RtContext *ctx)
+{
+    if (!ctx->paramsSet) return rt_fail(ctx, RT_E_STATE, "rt_set_params has not been called");
+    if (!ctx->built) return rt_fail(ctx, RT_E_STATE, "rt_bvh_build has not been called");
+    return RT_OK;
+}
+
+int rt_dispatch(RtContext *ctx)
+{
+    RT_ENTER(ctx);
+    int rc = ready_to_render(ctx);
+    if (rc) return rc;   // CustomRender returns silently when not initialised (RayTracing.cs:120-121); here it is an error code
+    return rt_dispatch_impl(ctx);
+}
+
+int rt_dispatch_shadowmap(RtContext *ctx)
+{
+    RT_ENTER(ctx);
+    int rc = ready_to_render(ctx);
+    if (rc) return rc;
+    return rt_shadowmap_impl(ctx);
+}
+
+int rt_accumulate(RtContext *ctx, uint32_t sample_per_pixel, int use_shadow_map)
+{
+    RT_ENTER(ctx);
+    if (!ctx->paramsSet) return rt_fail(ctx, RT_E_STATE, "rt_set_params has not been called");
+    return rt_accumulate_impl(ctx, sample_per_pixel, use_shadow_map);
+}
+
+int rt_render_frames(RtContext *ctx, const float *seeds, uint32_t n_frames)
+{
+    RT_ENTER(ctx);
+    int rc = ready_to_render(ctx);
+    if (rc) return rc;
+    if (n_frames && !seeds) return rt_fail(ctx, RT_E_INVALID, "null seeds");
+    const bool matte = (ctx->params.flags & RT_FLAG_MATTE_MASK) != 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    RT_HIP(ctx, hipEventCreate(&e0));
+    RT_HIP(ctx, hipEventCreate(&e1));
+    RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (uint32_t k = 0; k < n_frames; ++k) {
+        ctx->params.seed = seeds[k];
+        if ((rc = rt_dispatch_impl(ctx))) return rc;
+        if (matte && (rc = rt_shadowmap_impl(ctx))) return rc;
+        if ((rc = rt_accumulate_impl(ctx, ctx->sampleCount, matte ? 1 : 0))) return rc;
+        ctx->sampleCount++;
+    }
+    RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    ctx->renderMs = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    rt_timer_resolve(ctx);
+    return check_error_flag(ctx);
+}
+
+int rt_set_dirty(RtContext *ctx)
+{
+    if (!ctx) return RT_E_INVALID;
+    ctx->sampleCount = 0;
+    return RT_OK;
+}
+
+uint32_t rt_sample_count(RtContext *ctx) { return ctx ? ctx->sampleCount : 0; }
+uint32_t rt_local_pixel_count(RtContext *ctx) { return ctx && ctx->paramsSet ? ctx->tile.nSlots : 0; }
+
+static float4 *image_ptr(RtContext *ctx, int which)
+{
+    switch (which) {
+    case RT_IMAGE_RT: return ctx->dRt;
+    case RT_IMAGE_CONVERGED: return ctx->dConv;
+    case RT_IMAGE_SHADOWMAP: return ctx->dShadowMap;
+    default: return nullptr;
+    }
+}
+
+int rt_readback(RtContext *ctx, int which, float *dst_rgba)
+{
+    RT_ENTER(ctx);
+    if (!ctx->paramsSet) return rt_fail(ctx, RT_E_STATE, "rt_set_params has not been called");
+    float4 *src = image_ptr(ctx, which);
+    if (!src || !dst_rgba) return rt_fail(ctx, RT_E_INVALID, "bad image selector or null destination");
+    const size_t px = (size_t)ctx->params.width * ctx->params.height;
+    float4 *full = nullptr;
+    RT_HIP(ctx, hipMalloc((void **)&full, px * sizeof(float4)));
+    RT_HIP(ctx, hipMemsetAsync(full, 0, px * sizeof(float4), ctx->stream));
+    int rc = rt_expand_local_impl(ctx, src, full);
+    if (rc) return rc;
+    RT_HIP(ctx, hipMemcpyAsync(dst_rgba, full, px * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(full);
+    rt_timer_resolve(ctx);
+    return check_error_flag(ctx);
+}
+
+int rt_readback_local_device(RtContext *ctx, int which, void *device_dst)
+{
+    RT_ENTER(ctx);
+    if (!ctx->paramsSet) return rt_fail(ctx, RT_E_STATE, "rt_set_params has not been called");
+    float4 *src = image_ptr(ctx, which);
+    if (!src || !device_dst) return rt_fail(ctx, RT_E_INVALID, "bad image selector or null destination");
+    RT_HIP(ctx, hipMemcpyAsync(device_dst, src, (size_t)ctx->tile.nSlots * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_upload_converged(RtContext *ctx, const float *src_rgba, uint32_t sample_per_pixel)
+{
+    RT_ENTER(ctx);
+    if (!ctx->paramsSet) return rt_fail(ctx, RT_E_STATE, "rt_set_params has not been called");
+    if (!src_rgba) return rt_fail(ctx, RT_E_INVALID, "null source");
+    // full frame -> tile-local order on the host (rare, checkpoint restore only)
+    const uint32_t n = ctx->tile.nSlots;
+    std::vector<float> local((size_t)n * 4, 0.0f);
+    for (uint32_t s = 0; s < n; ++s) {
+        uint32_t px, py;
+        if (ctx->tile.slot_to_pixel(s, &px, &py)) memcpy(&local[(size_t)s * 4], src_rgba + ((size_t)py * ctx->params.width + px) * 4, 16);
+    }
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipMemcpy(ctx->dConv, local.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+    ctx->sampleCount = sample_per_pixel;
+    return RT_OK;
+}
+
+int rt_local_pixel_map(RtContext *ctx, uint32_t *dst)
+{
+    if (!ctx || !dst) return RT_E_INVALID;
+    if (!ctx->paramsSet) return rt_fail(ctx, RT_E_STATE, "rt_set_params has not been called");
+    for (uint32_t s = 0; s < ctx->tile.nSlots; ++s) {
+        uint32_t px, py;
+        dst[s] = ctx->tile.slot_to_pixel(s, &px, &py) ? py * (uint32_t)ctx->params.width + px : 0xFFFFFFFFu;
+    }
+    return RT_OK;
+}
+
+int rt_trace_rays_device(RtContext *ctx, const void *device_origins4, const void *device_dirs4, uint32_t n, void *device_hits4)
+{
+    RT_ENTER(ctx);
+    if (!ctx->built) return rt_fail(ctx, RT_E_STATE, "rt_bvh_build has not been called");
+    if (n && (!device_origins4 || !device_dirs4 || !device_hits4)) return rt_fail(ctx, RT_E_INVALID, "null ray buffers");
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    RT_HIP(ctx, hipEventCreate(&e0));
+    RT_HIP(ctx, hipEventCreate(&e1));
+    RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    int rc = rt_trace_device_impl(ctx, (const float4 *)device_origins4, (const float4 *)device_dirs4, n, (RtHitRec *)device_hits4);
+    if (rc) return rc;
+    RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    ctx->renderMs = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    rt_timer_resolve(ctx);
+    return check_error_flag(ctx);
+}
+
+int rt_trace_rays(RtContext *ctx, const float *origins, const float *directions, uint32_t n, float *out_t, uint32_t *out_triangle,
+                  float *out_u, float *out_v)
+{
+    RT_ENTER(ctx);
+    if (!ctx->built) return rt_fail(ctx, RT_E_STATE, "rt_bvh_build has not been called");
+    if (n == 0) return RT_OK;
+    if (!origins || !directions) return rt_fail(ctx, RT_E_INVALID, "null rays");
+    float *d3 = nullptr;       // [o(3n) | d(3n)]
+    float4 *d4 = nullptr;      // [o4(n) | d4(n)]
+    RtHitRec *dh = nullptr;
+    float *dout = nullptr;     // [t | tri | u | v] x n
+    RT_HIP(ctx, hipMalloc((void **)&d3, (size_t)n * 6 * 4));
+    RT_HIP(ctx, hipMalloc((void **)&d4, (size_t)n * 2 * sizeof(float4)));
+    RT_HIP(ctx, hipMalloc((void **)&dh, (size_t)n * sizeof(RtHitRec)));
+    RT_HIP(ctx, hipMalloc((void **)&dout, (size_t)n * 16));
+    RT_HIP(ctx, hipMemcpyAsync(d3, origins, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(d3 + (size_t)3 * n, directions, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+    int rc = rt_pack_rays_impl(ctx, d3, d3 + (size_t)3 * n, n, d4, d4 + n);
+    if (!rc) rc = rt_trace_device_impl(ctx, d4, d4 + n, n, dh);
+    if (!rc) rc = rt_hits_to_host_impl(ctx, dh, n, dout, (uint32_t *)(dout + n), dout + (size_t)2 * n, dout + (size_t)3 * n);
+    if (rc) return rc;
+    if (out_t) RT_HIP(ctx, hipMemcpyAsync(out_t, dout, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_triangle) RT_HIP(ctx, hipMemcpyAsync(out_triangle, dout + n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_u) RT_HIP(ctx, hipMemcpyAsync(out_u, dout + (size_t)2 * n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_v) RT_HIP(ctx, hipMemcpyAsync(out_v, dout + (size_t)3 * n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d3);
+    (void)hipFree(d4);
+    (void)hipFree(dh);
+    (void)hipFree(dout);
+    rt_timer_resolve(ctx);
+    return check_error_flag(ctx);
+}
+
+int rt_debug_eval(RtContext *ctx, int which, const float *x, const float *y, uint32_t n, float *out)
+{
+    RT_ENTER(ctx);
+    if (!x || !y || !out || n == 0) return rt_fail(ctx, RT_E_INVALID, "bad rt_debug_eval arguments");
+    const uint32_t nin = which == 7 ? 2u : n;
+    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    RT_HIP(ctx, hipMalloc((void **)&dx, (size_t)nin * 4));
+    RT_HIP(ctx, hipMalloc((void **)&dy, (size_t)nin * 4));
+    RT_HIP(ctx, hipMalloc((void **)&dout, (size_t)n * 4));
+    RT_HIP(ctx, hipMemcpyAsync(dx, x, (size_t)nin * 4, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(dy, y, (size_t)(which == 7 ? 1 : nin) * 4, hipMemcpyHostToDevice, ctx->stream));
+    int rc = rt_debug_eval_impl(ctx, which, dx, dy, n, dout);
+    if (rc) return rc;
+    RT_HIP(ctx, hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(dx);
+    (void)hipFree(dy);
+    (void)hipFree(dout);
+    return RT_OK;
+}
+
+int rt_enable_counters(RtContext *ctx, int enable)
+{
+    if (!ctx) return RT_E_INVALID;
+    ctx->countersOn = enable != 0;
+    return RT_OK;
+}
+
+int rt_enable_kernel_timing(RtContext *ctx, int enable)
+{
+    if (!ctx) return RT_E_INVALID;
+    rt_timer_resolve(ctx);
+    ctx->timingOn = enable != 0;
+    return RT_OK;
+}
+
+int rt_reset_stats(RtContext *ctx)
+{
+    RT_ENTER(ctx);
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rt_timer_resolve(ctx);
+    ctx->timers.clear();
+    RT_HIP(ctx, hipMemset(ctx->dStats, 0, 8 * sizeof(unsigned long long)));
+    return RT_OK;
+}
+
+int rt_get_stats(RtContext *ctx, RtStats *out)
+{
+    RT_ENTER(ctx);
+    if (!out) return rt_fail(ctx, RT_E_INVALID, "null stats");
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long h[8];
+    RT_HIP(ctx, hipMemcpy(h, ctx->dStats, sizeof h, hipMemcpyDeviceToHost));
+    out->rays = h[0];
+    out->internalVisits = h[1];
+    out->leafVisits = h[2];
+    out->triTests = h[3];
+    out->hits = h[4];
+    out->paths = h[5];
+    out->buildMs = ctx->buildMs;
+    out->renderMs = ctx->renderMs;
+    return RT_OK;
+}
+
+int rt_kernel_time(RtContext *ctx, const char *kernel_name, double *out_total_ms, uint64_t *out_launches)
+{
+    RT_ENTER(ctx);
+    if (!kernel_name) return rt_fail(ctx, RT_E_INVALID, "null kernel name");
+    rt_timer_resolve(ctx);
+    auto it = ctx->timers.find(kernel_name);
+    if (out_total_ms) *out_total_ms = it == ctx->timers.end() ? 0.0 : it->second.totalMs;
+    if (out_launches) *out_launches = it == ctx->timers.end() ? 0 : it->second.launches;
+    return RT_OK;
+}
+
+int rt_synchronize(RtContext *ctx)
+{
+    RT_ENTER(ctx);
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rt_timer_resolve(ctx);
+    return check_error_flag(ctx);
+}
+
+} // extern "C"

@@ -1,0 +1,615 @@
+// build.hip -- LBVH construction on gfx950: per-triangle boxes + Morton codes,
+// LDS radix sort, duplicate-key spreading, Karras tree, bottom-up box fit and
+// packing into the 64-byte traversal nodes.
+//
+// Reference path being replaced (results are bit-identical on the same input):
+//   Assets/Shaders/BVH/MeshData.compute:62-131          (k_calculate)
+//   Assets/Shaders/BVH/LocalRadixSort.compute, Scan.compute, GlobalRadixSort.compute,
+//   Assets/Scripts/BVH/ComputeBufferSorter.cs:105-131    (k_sort_*: stable LSD, 4 x 8 bit)
+//   Assets/Scripts/BVH/MeshBufferContainer.cs:92-107     (k_scan_* in dedup mode, on the GPU)
+//   Assets/Shaders/BVH/BVH.compute:94-142                (k_tree)
+//   Assets/Shaders/BVH/BVH.compute:164-211               (k_fit, level-synchronous, no atomics)
+#include "rt_internal.h"
+
+#define WAVE 64
+#define SORT_THREADS 256
+#define SORT_ITEMS 16
+#define SORT_TILE (SORT_THREADS * SORT_ITEMS)
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 16
+#define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
+#define FIT_UNDONE 0xFFFFFFFFu
+
+// ------------------------------------------------------------------ calculate
+__device__ inline uint32_t expand_bits(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+__device__ inline uint32_t morton_code(rt_f3 v)
+{
+    v.x = rt_min(rt_max(v.x * 1024.0f, 0.0f), 1023.0f);
+    v.y = rt_min(rt_max(v.y * 1024.0f, 0.0f), 1023.0f);
+    v.z = rt_min(rt_max(v.z * 1024.0f, 0.0f), 1023.0f);
+    const uint32_t xx = expand_bits(rt_ftou(v.x));
+    const uint32_t yy = expand_bits(rt_ftou(v.y));
+    const uint32_t zz = expand_bits(rt_ftou(v.z));
+    return xx * 4 + yy * 2 + zz;
+}
+
+__global__ __launch_bounds__(256) void k_calculate(const uint32_t *__restrict__ idx, const float *__restrict__ verts,
+                                                    uint32_t N, float4 *__restrict__ triAABB,
+                                                    uint32_t *__restrict__ morton, uint32_t *__restrict__ triIndex)
+{
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= N) return;
+    const uint32_t i0 = idx[id * 3 + 0], i1 = idx[id * 3 + 1], i2 = idx[id * 3 + 2];
+    const float *a = verts + (size_t)i0 * 11, *b = verts + (size_t)i1 * 11, *c = verts + (size_t)i2 * 11;
+    const rt_f3 p0 = rt_mk3(a[0], a[1], a[2]), p1 = rt_mk3(b[0], b[1], b[2]), p2 = rt_mk3(c[0], c[1], c[2]);
+    const rt_f3 mn = rt_mk3(rt_min(rt_min(p0.x, p1.x), p2.x) - 0.001f, rt_min(rt_min(p0.y, p1.y), p2.y) - 0.001f,
+                            rt_min(rt_min(p0.z, p1.z), p2.z) - 0.001f);
+    const rt_f3 mx = rt_mk3(rt_max(rt_max(p0.x, p1.x), p2.x) + 0.001f, rt_max(rt_max(p0.y, p1.y), p2.y) + 0.001f,
+                            rt_max(rt_max(p0.z, p1.z), p2.z) + 0.001f);
+    triAABB[id * 2 + 0] = make_float4(mn.x, mn.y, mn.z, 0.0f);
+    triAABB[id * 2 + 1] = make_float4(mx.x, mx.y, mx.z, 0.0f);
+    // Fixed +-125 world box (MeshBufferContainer.cs:9-14,73-77), not the mesh bounds.
+    const rt_f3 encMin = rt_mk3(-125.0f, -125.0f, -125.0f), encMax = rt_mk3(125.0f, 125.0f, 125.0f);
+    const rt_f3 center = rt_scale3(rt_add3(mn, mx), 0.5f);
+    const rt_f3 normalized = rt_div3(rt_sub3(center, encMin), rt_sub3(encMax, encMin));
+    morton[id] = morton_code(normalized);
+    triIndex[id] = id;
+}
+
+// ------------------------------------------------------------------ block scan helper
+// Exclusive scan of one value per thread over a block of up to 1024 threads.
+__device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t *waveSums /* LDS, >= 17 */, uint32_t *total)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, nw = (blockDim.x + 63u) >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off, WAVE);
+        if (lane >= (uint32_t)off) inc += t;
+    }
+    if (lane == 63u) waveSums[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t w = 0; w < nw; ++w) {
+            const uint32_t t = waveSums[w];
+            waveSums[w] = run;
+            run += t;
+        }
+        waveSums[16] = run;
+    }
+    __syncthreads();
+    const uint32_t res = waveSums[wave] + inc - v;
+    *total = waveSums[16];
+    __syncthreads();
+    return res;
+}
+
+// ------------------------------------------------------------------ scan (3 kernels)
+// MODE 0: out[i] = sum_{j<i} in[j]            (exclusive, plain)
+// MODE 1: f(0) = 0, f(i) = max(in[i]-in[i-1], 1); out[i] = sum_{j<=i} f(j)
+//         = DistributeMortonCode (MeshBufferContainer.cs:92-107) in u32 arithmetic.
+template <int MODE>
+__device__ inline uint32_t scan_value(const uint32_t *__restrict__ in, uint32_t i)
+{
+    if (MODE == 0) return in[i];
+    if (i == 0) return 0u;
+    const uint32_t d = in[i] - in[i - 1];
+    return d > 1u ? d : 1u;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const uint32_t *__restrict__ in, uint32_t M,
+                                                               uint32_t *__restrict__ blockSums)
+{
+    __shared__ uint32_t ws[17];
+    const uint32_t base = blockIdx.x * SCAN_TILE;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const uint32_t i = base + k * SCAN_THREADS + threadIdx.x;
+        if (i < M) s += scan_value<MODE>(in, i);
+    }
+    uint32_t total;
+    block_exclusive_scan(s, ws, &total);
+    if (threadIdx.x == 0) blockSums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_sums(uint32_t *__restrict__ sums, uint32_t n)
+{
+    __shared__ uint32_t ws[17];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? sums[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, ws, &total);
+        if (i < n) sums[i] = carry + ex;
+        carry += total;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                              uint32_t M, const uint32_t *__restrict__ blockSums)
+{
+    __shared__ uint32_t ws[17];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;  // blocked: 16 consecutive per thread
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const uint32_t i = base + k;
+        v[k] = i < M ? scan_value<MODE>(in, i) : 0u;
+        s += v[k];
+    }
+    uint32_t total;
+    uint32_t run = block_exclusive_scan(s, ws, &total) + blockSums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const uint32_t i = base + k;
+        if (MODE == 0) {
+            if (i < M) out[i] = run;
+            run += v[k];
+        } else {
+            run += v[k];
+            if (i < M) out[i] = run;
+        }
+    }
+}
+
+template <int MODE>
+static void launch_scan(RtContext *ctx, const uint32_t *in, uint32_t *out, uint32_t M, uint32_t *blockSums)
+{
+    const uint32_t nb = (M + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL((k_scan_reduce<MODE>), dim3(nb), dim3(SCAN_THREADS), 0, ctx->stream, in, M, blockSums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, blockSums, nb);
+    hipLaunchKernelGGL((k_scan_apply<MODE>), dim3(nb), dim3(SCAN_THREADS), 0, ctx->stream, in, out, M, blockSums);
+}
+
+// ------------------------------------------------------------------ radix sort
+// Tile = 4096 keys per 256-thread block.  Wave w owns keys [w*1024,(w+1)*1024)
+// of the tile and walks them in 16 rounds of 64 consecutive keys, so that
+// (wave, round, lane) order == memory order == the order stability refers to.
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_hist(const uint32_t *__restrict__ keys, uint32_t n, int shift,
+                                                             uint32_t *__restrict__ blockHist, uint32_t nb)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * SORT_TILE;
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const uint32_t i = base + r * SORT_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    blockHist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];   // digit-major
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_scatter(const uint32_t *__restrict__ keysIn,
+                                                                const uint32_t *__restrict__ valsIn,
+                                                                uint32_t *__restrict__ keysOut,
+                                                                uint32_t *__restrict__ valsOut, uint32_t n, int shift,
+                                                                const uint32_t *__restrict__ scanned, uint32_t nb)
+{
+    __shared__ uint32_t waveCount[4][256];
+    __shared__ uint32_t base[256];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    for (uint32_t i = tid; i < 1024; i += SORT_THREADS) (&waveCount[0][0])[i] = 0;
+    __syncthreads();
+
+    uint32_t key[SORT_ITEMS], rank[SORT_ITEMS];
+    const uint32_t tileBase = blockIdx.x * SORT_TILE + wave * (SORT_ITEMS * WAVE);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const uint32_t i = tileBase + r * WAVE + lane;
+        const bool valid = i < n;
+        const uint32_t k = valid ? keysIn[i] : 0xFFFFFFFFu;
+        const uint32_t d = (k >> shift) & 255u;
+        // lanes of this wave holding the same digit (wave64 ballots, one per bit)
+        unsigned long long mask = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            mask &= bit ? bal : ~bal;
+        }
+        const uint32_t rnk = __popcll(mask & lt);
+        const uint32_t cnt = __popcll(mask);
+        uint32_t prev = 0;
+        if (valid && rnk == 0) prev = atomicAdd(&waveCount[wave][d], cnt);   // one leader per digit group
+        const int leader = valid ? (__ffsll((long long)mask) - 1) : (int)lane;
+        prev = __shfl(prev, leader, WAVE);
+        rank[r] = prev + rnk;
+        key[r] = k;
+    }
+    __syncthreads();
+    {   // exclusive prefix over the 4 waves per digit + global base of (digit, block)
+        const uint32_t d = tid;
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t t = waveCount[w][d];
+            waveCount[w][d] = run;
+            run += t;
+        }
+        base[d] = scanned[d * nb + blockIdx.x];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; ++r) {
+        const uint32_t i = tileBase + r * WAVE + lane;
+        if (i < n) {
+            const uint32_t d = (key[r] >> shift) & 255u;
+            const uint32_t dst = base[d] + waveCount[wave][d] + rank[r];
+            keysOut[dst] = key[r];
+            valsOut[dst] = valsIn[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ tree (Karras 2012)
+__device__ inline int delta_codes(const uint32_t *__restrict__ codes, int x, int y, int numObjects)
+{
+    if (x >= 0 && x <= numObjects - 1 && y >= 0 && y <= numObjects - 1) {
+        const uint32_t v = codes[x] ^ codes[y];
+        return v == 0 ? 32 : __clz((int)v);
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(256) void k_tree(const uint32_t *__restrict__ codes, uint32_t N, uint32_t *__restrict__ left,
+                                               uint32_t *__restrict__ right, uint32_t *__restrict__ parent,
+                                               uint32_t *__restrict__ leafParent)
+{
+    const uint32_t threadId = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadId >= N - 1) return;
+    const int numObjects = (int)N, idx = (int)threadId;
+    // DetermineRange (BVH.compute:35-52); uint products wrap modulo 2^32 as in the shader
+    const int dd = delta_codes(codes, idx, idx + 1, numObjects) - delta_codes(codes, idx, idx - 1, numObjects);
+    const int d = dd > 0 ? 1 : (dd < 0 ? -1 : 0);
+    const int dmin = delta_codes(codes, idx, idx - d, numObjects);
+    uint32_t lmax = 2;
+    while (delta_codes(codes, idx, (int)((uint32_t)idx + lmax * (uint32_t)d), numObjects) > dmin) lmax *= 2;
+    int l = 0;
+    for (uint32_t t = lmax / 2; t >= 1; t /= 2)
+        if (delta_codes(codes, idx, (int)((uint32_t)idx + ((uint32_t)l + t) * (uint32_t)d), numObjects) > dmin) l += (int)t;
+    const int j = idx + l * d;
+    const int first = idx < j ? idx : j, last = idx < j ? j : idx;
+    // FindSplit (BVH.compute:54-92)
+    int split;
+    {
+        const uint32_t firstCode = codes[first], lastCode = codes[last];
+        if (firstCode == lastCode) {
+            split = (first + last) >> 1;
+        } else {
+            const int commonPrefix = __clz((int)(firstCode ^ lastCode));
+            split = first;
+            int step = last - first;
+            do {
+                step = (step + 1) >> 1;
+                const int newSplit = split + step;
+                if (newSplit < last) {
+                    const uint32_t x = firstCode ^ codes[newSplit];
+                    const int splitPrefix = x == 0 ? 32 : __clz((int)x);
+                    if (splitPrefix > commonPrefix) split = newSplit;
+                }
+            } while (step > 1);
+        }
+    }
+    if (split == first) {
+        leafParent[split] = threadId;
+        left[threadId] = (uint32_t)split | RT_LEAF_BIT;
+    } else {
+        parent[split] = threadId;
+        left[threadId] = (uint32_t)split;
+    }
+    if (split + 1 == last) {
+        leafParent[split + 1] = threadId;
+        right[threadId] = (uint32_t)(split + 1) | RT_LEAF_BIT;
+    } else {
+        parent[split + 1] = threadId;
+        right[threadId] = (uint32_t)(split + 1);
+    }
+}
+
+// ------------------------------------------------------------------ bottom-up fit
+// One launch per tree level: a node is computed in launch `iter` when both of
+// its internal children were completed in an EARLIER launch (their `done` word
+// is < iter), so every read of a child box is ordered by a kernel boundary and
+// no atomics or fences are needed.  The union itself is min/max only, hence
+// identical to the reference's atomic-flag walk whatever the order.
+__global__ __launch_bounds__(256) void k_fit(uint32_t N, uint32_t iter, const uint32_t *__restrict__ left,
+                                              const uint32_t *__restrict__ right, const uint32_t *__restrict__ sortedIdx,
+                                              const float4 *__restrict__ triAABB, float4 *bvhData, uint32_t *done,
+                                              float4 *__restrict__ nodes, uint32_t *__restrict__ remaining)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N - 1) return;
+    if (done[i] != FIT_UNDONE) return;
+    const uint32_t l = left[i], r = right[i];
+    const bool lLeaf = l & RT_LEAF_BIT, rLeaf = r & RT_LEAF_BIT;
+    const uint32_t li = l & ~RT_LEAF_BIT, ri = r & ~RT_LEAF_BIT;
+    if (!lLeaf && done[li] >= iter) return;
+    if (!rLeaf && done[ri] >= iter) return;
+    float4 lmn, lmx, rmn, rmx;
+    if (lLeaf) { const uint32_t t = sortedIdx[li]; lmn = triAABB[t * 2]; lmx = triAABB[t * 2 + 1]; }
+    else       { lmn = bvhData[li * 2]; lmx = bvhData[li * 2 + 1]; }
+    if (rLeaf) { const uint32_t t = sortedIdx[ri]; rmn = triAABB[t * 2]; rmx = triAABB[t * 2 + 1]; }
+    else       { rmn = bvhData[ri * 2]; rmx = bvhData[ri * 2 + 1]; }
+    bvhData[i * 2 + 0] = make_float4(rt_min(lmn.x, rmn.x), rt_min(lmn.y, rmn.y), rt_min(lmn.z, rmn.z), 0.0f);
+    bvhData[i * 2 + 1] = make_float4(rt_max(lmx.x, rmx.x), rt_max(lmx.y, rmx.y), rt_max(lmx.z, rmx.z), 0.0f);
+    nodes[i * 4 + 0] = make_float4(lmn.x, lmn.y, lmn.z, lmx.x);
+    nodes[i * 4 + 1] = make_float4(lmx.y, lmx.z, rmn.x, rmn.y);
+    nodes[i * 4 + 2] = make_float4(rmn.z, rmx.x, rmx.y, rmx.z);
+    nodes[i * 4 + 3] = make_float4(__uint_as_float(l), __uint_as_float(r), 0.0f, 0.0f);
+    done[i] = iter;
+    atomicSub(remaining, 1u);
+}
+
+// ------------------------------------------------------------------ leaf packing
+__global__ __launch_bounds__(256) void k_pack_leaves(uint32_t N, const uint32_t *__restrict__ sortedIdx,
+                                                      const uint32_t *__restrict__ idx, const float *__restrict__ verts,
+                                                      const uint32_t *__restrict__ matIdx, const int32_t *__restrict__ shadow,
+                                                      float4 *__restrict__ leafTri, float4 *__restrict__ leafShade)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const uint32_t t = sortedIdx[j];
+    const uint32_t i0 = idx[t * 3 + 0], i1 = idx[t * 3 + 1], i2 = idx[t * 3 + 2];
+    const float *a = verts + (size_t)i0 * 11, *b = verts + (size_t)i1 * 11, *c = verts + (size_t)i2 * 11;
+    const rt_f3 v0 = rt_mk3(a[0], a[1], a[2]);
+    const rt_f3 e1 = rt_sub3(rt_mk3(b[0], b[1], b[2]), v0);
+    const rt_f3 e2 = rt_sub3(rt_mk3(c[0], c[1], c[2]), v0);
+    leafTri[j * 3 + 0] = make_float4(v0.x, v0.y, v0.z, e1.x);
+    leafTri[j * 3 + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+    leafTri[j * 3 + 2] = make_float4(e2.z, __uint_as_float(t), 0.0f, 0.0f);
+    leafShade[j * 3 + 0] = make_float4(a[3], a[4], a[5], b[3]);
+    leafShade[j * 3 + 1] = make_float4(b[4], b[5], c[3], c[4]);
+    leafShade[j * 3 + 2] = make_float4(c[5], __uint_as_float(matIdx[t]), __int_as_float(shadow[t * 2 + 0]), 0.0f);
+}
+
+// ------------------------------------------------------------------ wire-struct readback kernels
+__global__ void k_wire_nodes(uint32_t N, const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
+                             const uint32_t *__restrict__ parent, const uint32_t *__restrict__ leafParent,
+                             RtInternalNode *__restrict__ inodes, RtLeafNode *__restrict__ leaves)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) {
+        RtLeafNode ln;
+        ln.parent = leafParent[i];
+        ln.index = i;
+        leaves[i] = ln;
+    }
+    if (i + 1 < N) {
+        RtInternalNode n;
+        const uint32_t l = left[i], r = right[i];
+        n.leftNode = l & ~RT_LEAF_BIT;
+        n.leftNodeType = (l & RT_LEAF_BIT) ? RT_LEAF_NODE : RT_INTERNAL_NODE;
+        n.rightNode = r & ~RT_LEAF_BIT;
+        n.rightNodeType = (r & RT_LEAF_BIT) ? RT_LEAF_NODE : RT_INTERNAL_NODE;
+        n.parent = parent[i];
+        n.index = i;
+        inodes[i] = n;
+    }
+}
+
+// MeshData.compute:108-130: the 192-byte Triangle record, produced on demand.
+__global__ void k_wire_triangles(uint32_t N, const uint32_t *__restrict__ idx, const float *__restrict__ verts,
+                                 const uint32_t *__restrict__ matIdx, const int32_t *__restrict__ shadow,
+                                 RtTriangle *__restrict__ out)
+{
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= N) return;
+    RtTriangle t;
+    memset(&t, 0, sizeof t);
+    const float *v[3];
+    for (int k = 0; k < 3; ++k) v[k] = verts + (size_t)idx[id * 3 + k] * 11;
+    for (int c = 0; c < 3; ++c) {
+        t.point0[c] = v[0][c]; t.point1[c] = v[1][c]; t.point2[c] = v[2][c];
+        t.normal0[c] = v[0][3 + c]; t.normal1[c] = v[1][3 + c]; t.normal2[c] = v[2][3 + c];
+        t.tangent0[c] = v[0][6 + c]; t.tangent1[c] = v[1][6 + c]; t.tangent2[c] = v[2][6 + c];
+    }
+    for (int c = 0; c < 2; ++c) { t.uv0[c] = v[0][9 + c]; t.uv1[c] = v[1][9 + c]; t.uv2[c] = v[2][9 + c]; }
+    t.materialIndex = (int32_t)matIdx[id];
+    t.castShadow = shadow[id * 2 + 0];
+    t.receiveShadow = shadow[id * 2 + 0];      // MeshData.compute:127-128 reads [0] twice
+    out[id] = t;
+}
+
+// ------------------------------------------------------------------ host orchestration
+void rt_free_build(RtContext *ctx)
+{
+    void **ptrs[] = {(void **)&ctx->dTriAABB, (void **)&ctx->dMortonUnsorted, (void **)&ctx->dMortonSortedRaw,
+                     (void **)&ctx->dMorton, (void **)&ctx->dSortedIdx, (void **)&ctx->dLeft, (void **)&ctx->dRight,
+                     (void **)&ctx->dParent, (void **)&ctx->dLeafParent, (void **)&ctx->dBvhData, (void **)&ctx->dNodes,
+                     (void **)&ctx->dLeafTri, (void **)&ctx->dLeafShade};
+    for (void **p : ptrs) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    ctx->built = false;
+}
+
+template <typename T>
+static hipError_t dalloc(T **p, size_t count)
+{
+    return hipMalloc((void **)p, (count ? count : 1) * sizeof(T));
+}
+
+int rt_build_impl(RtContext *ctx)
+{
+    const uint32_t N = ctx->N;
+    rt_free_build(ctx);
+    memset(&ctx->rootBox, 0, sizeof ctx->rootBox);
+    if (N == 0) {
+        ctx->built = true;
+        return RT_OK;
+    }
+    const uint32_t NI = N - 1;
+    uint32_t *keysB = nullptr, *valsB = nullptr, *blockHist = nullptr, *scanSums = nullptr, *done = nullptr, *remaining = nullptr;
+    const uint32_t nbSort = (N + SORT_TILE - 1) / SORT_TILE;
+    const uint32_t histLen = 256u * nbSort;
+    const uint32_t nbScanMax = ((histLen > N ? histLen : N) + SCAN_TILE - 1) / SCAN_TILE;
+
+    RT_HIP(ctx, dalloc(&ctx->dTriAABB, (size_t)N));
+    RT_HIP(ctx, dalloc(&ctx->dMortonUnsorted, (size_t)N));
+    RT_HIP(ctx, dalloc(&ctx->dMortonSortedRaw, (size_t)N));
+    RT_HIP(ctx, dalloc(&ctx->dMorton, (size_t)N));
+    RT_HIP(ctx, dalloc(&ctx->dSortedIdx, (size_t)N));
+    RT_HIP(ctx, dalloc(&ctx->dLeft, (size_t)NI));
+    RT_HIP(ctx, dalloc(&ctx->dRight, (size_t)NI));
+    RT_HIP(ctx, dalloc(&ctx->dParent, (size_t)NI));
+    RT_HIP(ctx, dalloc(&ctx->dLeafParent, (size_t)N));
+    RT_HIP(ctx, dalloc(&ctx->dBvhData, (size_t)NI));
+    RT_HIP(ctx, dalloc(&ctx->dNodes, (size_t)NI));
+    RT_HIP(ctx, dalloc(&ctx->dLeafTri, (size_t)N));
+    RT_HIP(ctx, dalloc(&ctx->dLeafShade, (size_t)N));
+    RT_HIP(ctx, dalloc(&keysB, (size_t)N));
+    RT_HIP(ctx, dalloc(&valsB, (size_t)N));
+    RT_HIP(ctx, dalloc(&blockHist, (size_t)histLen));
+    RT_HIP(ctx, dalloc(&scanSums, (size_t)nbScanMax + 1));
+    RT_HIP(ctx, dalloc(&done, (size_t)NI));
+    RT_HIP(ctx, dalloc(&remaining, (size_t)1));
+
+    hipStream_t st = ctx->stream;
+    hipEvent_t e0, e1;
+    RT_HIP(ctx, hipEventCreate(&e0));
+    RT_HIP(ctx, hipEventCreate(&e1));
+    RT_HIP(ctx, hipEventRecord(e0, st));
+
+    const dim3 blk(256);
+    const dim3 gridN((N + 255) / 256), gridNI((NI + 255) / 256);
+    uint32_t *keysA = ctx->dMortonSortedRaw, *valsA = ctx->dSortedIdx;
+
+    rt_timer_begin(ctx, "k_calculate");
+    hipLaunchKernelGGL(k_calculate, gridN, blk, 0, st, ctx->dIdx, (const float *)ctx->dVerts, N, (float4 *)ctx->dTriAABB,
+                       ctx->dMortonUnsorted, valsA);
+    rt_timer_end(ctx);
+    RT_HIP(ctx, hipMemcpyAsync(keysA, ctx->dMortonUnsorted, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
+
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = pass * 8;
+        rt_timer_begin(ctx, "k_sort_hist");
+        hipLaunchKernelGGL(k_sort_hist, dim3(nbSort), dim3(SORT_THREADS), 0, st, keysA, N, shift, blockHist, nbSort);
+        rt_timer_end(ctx);
+        launch_scan<0>(ctx, blockHist, blockHist, histLen, scanSums);
+        rt_timer_begin(ctx, "k_sort_scatter");
+        hipLaunchKernelGGL(k_sort_scatter, dim3(nbSort), dim3(SORT_THREADS), 0, st, keysA, valsA, keysB, valsB, N, shift,
+                           blockHist, nbSort);
+        rt_timer_end(ctx);
+        uint32_t *t = keysA; keysA = keysB; keysB = t;
+        t = valsA; valsA = valsB; valsB = t;
+    }
+    // 4 passes: the result is back in dMortonSortedRaw / dSortedIdx.
+
+    launch_scan<1>(ctx, ctx->dMortonSortedRaw, ctx->dMorton, N, scanSums);
+
+    if (N >= 2) {
+        RT_HIP(ctx, hipMemsetAsync(ctx->dParent, 0xFF, (size_t)NI * 4, st));
+        RT_HIP(ctx, hipMemsetAsync(ctx->dLeafParent, 0xFF, (size_t)N * 4, st));
+        rt_timer_begin(ctx, "k_tree");
+        hipLaunchKernelGGL(k_tree, gridNI, blk, 0, st, ctx->dMorton, N, ctx->dLeft, ctx->dRight, ctx->dParent,
+                           ctx->dLeafParent);
+        rt_timer_end(ctx);
+        RT_HIP(ctx, hipMemsetAsync(done, 0xFF, (size_t)NI * 4, st));
+        RT_HIP(ctx, hipMemcpyAsync(remaining, &NI, 4, hipMemcpyHostToDevice, st));
+        uint32_t left = NI;
+        // Tree height <= 32 (strictly growing common prefix of unique 32-bit keys);
+        // check the remaining-node counter every 8 levels to stop early.
+        for (uint32_t iter = 0; iter < 40 && left != 0; ++iter) {
+            rt_timer_begin(ctx, "k_fit");
+            hipLaunchKernelGGL(k_fit, gridNI, blk, 0, st, N, iter, ctx->dLeft, ctx->dRight, ctx->dSortedIdx,
+                               (const float4 *)ctx->dTriAABB, (float4 *)ctx->dBvhData, done, (float4 *)ctx->dNodes, remaining);
+            rt_timer_end(ctx);
+            if ((iter & 7u) == 7u) {
+                RT_HIP(ctx, hipMemcpyAsync(&left, remaining, 4, hipMemcpyDeviceToHost, st));
+                RT_HIP(ctx, hipStreamSynchronize(st));
+            }
+        }
+        RT_HIP(ctx, hipMemcpyAsync(&left, remaining, 4, hipMemcpyDeviceToHost, st));
+        RT_HIP(ctx, hipStreamSynchronize(st));
+        if (left != 0) return rt_fail(ctx, RT_E_STATE, "BVH fit did not converge (%u nodes left)", left);
+        RT_HIP(ctx, hipMemcpyAsync(&ctx->rootBox, ctx->dBvhData, sizeof(RtAABB), hipMemcpyDeviceToHost, st));
+    } else {
+        RT_HIP(ctx, hipMemsetAsync(ctx->dLeafParent, 0xFF, (size_t)N * 4, st));
+    }
+    rt_timer_begin(ctx, "k_pack_leaves");
+    hipLaunchKernelGGL(k_pack_leaves, gridN, blk, 0, st, N, ctx->dSortedIdx, ctx->dIdx, (const float *)ctx->dVerts,
+                       ctx->dMatIdx, ctx->dShadow, (float4 *)ctx->dLeafTri, (float4 *)ctx->dLeafShade);
+    rt_timer_end(ctx);
+
+    RT_HIP(ctx, hipEventRecord(e1, st));
+    RT_HIP(ctx, hipStreamSynchronize(st));
+    RT_HIP(ctx, hipGetLastError());
+    float ms = 0;
+    RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    ctx->buildMs = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(keysB);
+    (void)hipFree(valsB);
+    (void)hipFree(blockHist);
+    (void)hipFree(scanSums);
+    (void)hipFree(done);
+    (void)hipFree(remaining);
+    ctx->built = true;
+    return RT_OK;
+}
+
+template <typename T>
+static int fetch(RtContext *ctx, T *dst, const T *src, size_t count)
+{
+    if (!dst || count == 0) return RT_OK;
+    RT_HIP(ctx, hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    return RT_OK;
+}
+
+int rt_readback_bvh_impl(RtContext *ctx, uint32_t *morton, uint32_t *sortedIdx, RtAABB *triAABB, RtTriangle *tris,
+                         RtInternalNode *inodes, RtLeafNode *leaves, RtAABB *bvhData)
+{
+    const uint32_t N = ctx->N;
+    if (N == 0) return RT_OK;
+    int rc;
+    if ((rc = fetch(ctx, morton, ctx->dMorton, N))) return rc;
+    if ((rc = fetch(ctx, sortedIdx, ctx->dSortedIdx, N))) return rc;
+    if ((rc = fetch(ctx, triAABB, ctx->dTriAABB, N))) return rc;
+    if ((rc = fetch(ctx, bvhData, ctx->dBvhData, N - 1))) return rc;
+    RtInternalNode *dI = nullptr;
+    RtLeafNode *dL = nullptr;
+    RtTriangle *dT = nullptr;
+    if (inodes || leaves) {
+        RT_HIP(ctx, dalloc(&dI, (size_t)N));
+        RT_HIP(ctx, dalloc(&dL, (size_t)N));
+        if (N >= 2) {
+            hipLaunchKernelGGL(k_wire_nodes, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, N, ctx->dLeft, ctx->dRight,
+                               ctx->dParent, ctx->dLeafParent, dI, dL);
+        } else {
+            RT_HIP(ctx, hipMemsetAsync(dL, 0xFF, sizeof(RtLeafNode), ctx->stream));  // never linked: stays NullLeaf
+        }
+        if ((rc = fetch(ctx, inodes, dI, N - 1))) return rc;
+        if ((rc = fetch(ctx, leaves, dL, N))) return rc;
+    }
+    if (tris) {
+        RT_HIP(ctx, dalloc(&dT, (size_t)N));
+        hipLaunchKernelGGL(k_wire_triangles, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, N, ctx->dIdx,
+                           (const float *)ctx->dVerts, ctx->dMatIdx, ctx->dShadow, dT);
+        if ((rc = fetch(ctx, tris, dT, N))) return rc;
+    }
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipGetLastError());
+    if (dI) (void)hipFree(dI);
+    if (dL) (void)hipFree(dL);
+    if (dT) (void)hipFree(dT);
+    return RT_OK;
+}

@@ -1,0 +1,197 @@
+// rt_internal.h -- device-side layouts and the context of librtcore.so.
+// Internal to the library; the public surface is include/rtcore.h.
+#ifndef RT_INTERNAL_H_
+#define RT_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_math.h"
+#include "../../include/rtcore.h"
+
+#define RT_LEAF_BIT 0x80000000u
+#define RT_INVALID 0xFFFFFFFFu
+#define RT_STACK_DEPTH 32   // Karras tree over unique 32-bit keys: depth <= 32
+
+// ---- traversal layouts (HBM) ----------------------------------------------
+// One internal node, 64 B, holding BOTH children's boxes so that a visit costs
+// one 64-byte fetch.  A child's box is the box the reference would test when
+// it pops that child (internal: bvhData[child]; leaf: triangleAABB[tri]).
+struct __attribute__((aligned(16))) RtNode64 {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    uint32_t left, right;      // index | RT_LEAF_BIT
+    uint32_t pad0, pad1;
+};
+static_assert(sizeof(RtNode64) == 64, "node layout");
+
+// Intersection record of the triangle at sorted leaf j: v0 and the two edge
+// vectors (the same subtractions IntersectTriangle_MT97 performs first).
+struct __attribute__((aligned(16))) RtLeafTri {
+    float v0[3], e1[3], e2[3];
+    uint32_t tri;              // original triangle index
+    uint32_t pad0, pad1;
+};
+static_assert(sizeof(RtLeafTri) == 48, "leaf layout");
+
+// Shading record of the triangle at sorted leaf j.
+struct __attribute__((aligned(16))) RtLeafShade {
+    float n0[3], n1[3], n2[3];
+    uint32_t material;
+    int32_t castShadow;
+    uint32_t pad0;
+};
+static_assert(sizeof(RtLeafShade) == 48, "shade layout");
+
+struct RtHitRec {              // 16 B: result of one BVHRayTrace
+    float t, u, v;
+    uint32_t leaf;             // sorted leaf index, RT_INVALID on miss
+};
+
+// Pointers a traversal / shading kernel needs, passed by value.
+struct RtSceneView {
+    const RtNode64 *nodes;
+    const RtLeafTri *leafTri;
+    const RtLeafShade *leafShade;
+    const RtMaterialData *materials;
+    uint32_t nMaterials;
+    uint32_t nTriangles;
+    RtAABB rootBox;            // bvhData[0] (zero box when N < 2)
+    const RtSphereLight *sphereLights;
+    const RtAreaLight *areaLights;
+    uint32_t nSphere, nArea;
+    const float4 *cube;
+    uint32_t cubeSize;
+    unsigned long long *stats; // 8 counters or nullptr
+    uint32_t *errorFlag;
+};
+
+// Tile-local slot -> global pixel mapping (see RtParams in rtcore.h).
+struct RtTileMap {
+    int width, height;
+    int tileSize, tilesX, tilesY;
+    int rank, count;
+    uint32_t nLocalTiles;
+    uint32_t nSlots;           // nLocalTiles * tileSize^2
+
+    __host__ __device__ inline bool slot_to_pixel(uint32_t slot, uint32_t *px, uint32_t *py) const
+    {
+        const uint32_t ts2 = (uint32_t)(tileSize * tileSize);
+        const uint32_t k = slot / ts2, within = slot % ts2;
+        const uint32_t t = k * (uint32_t)count + (uint32_t)rank;
+        const uint32_t tx = t % (uint32_t)tilesX, ty = t / (uint32_t)tilesX;
+        const uint32_t b = within >> 6, l = within & 63u;
+        const uint32_t bpr = (uint32_t)tileSize >> 3;
+        const uint32_t x = tx * tileSize + (b % bpr) * 8 + (l & 7u);
+        const uint32_t y = ty * tileSize + (b / bpr) * 8 + (l >> 3);
+        *px = x;
+        *py = y;
+        return x < (uint32_t)width && y < (uint32_t)height;
+    }
+};
+
+struct RtKernelTimer {
+    double totalMs = 0;
+    uint64_t launches = 0;
+};
+
+struct RtPendingEvent {
+    std::string name;
+    hipEvent_t start, stop;
+};
+
+struct RtContext {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // inputs
+    RtMeshVertex *dVerts = nullptr;
+    uint32_t nVerts = 0;
+    uint32_t *dIdx = nullptr;
+    uint32_t *dMatIdx = nullptr;
+    int32_t *dShadow = nullptr;
+    uint32_t N = 0;
+    RtMaterialData *dMats = nullptr;
+    uint32_t nMats = 0;
+    RtSphereLight *dSphere = nullptr;
+    RtAreaLight *dArea = nullptr;
+    RtDiscLight *dDisc = nullptr;
+    uint32_t nSphere = 0, nArea = 0, nDisc = 0;
+    float4 *dCube = nullptr;
+    uint32_t cubeSize = 0;
+
+    // build products
+    RtAABB *dTriAABB = nullptr;
+    uint32_t *dMortonUnsorted = nullptr, *dMortonSortedRaw = nullptr, *dMorton = nullptr;
+    uint32_t *dSortedIdx = nullptr;
+    uint32_t *dLeft = nullptr, *dRight = nullptr, *dParent = nullptr, *dLeafParent = nullptr;
+    RtAABB *dBvhData = nullptr;
+    RtNode64 *dNodes = nullptr;
+    RtLeafTri *dLeafTri = nullptr;
+    RtLeafShade *dLeafShade = nullptr;
+    RtAABB rootBox;
+    bool built = false;
+
+    // render state
+    RtParams params;
+    bool paramsSet = false;
+    RtTileMap tile;
+    uint32_t allocSlots = 0;
+    float4 *dRt = nullptr, *dConv = nullptr, *dShadowMap = nullptr;
+    float4 *dPo = nullptr, *dPd = nullptr, *dPe = nullptr;
+    uint2 *dRng = nullptr;
+    RtHitRec *dHit = nullptr;
+    uint32_t *dQueue[2] = {nullptr, nullptr};
+    uint32_t *dQCount = nullptr;          // RT_MAX_BOUNCE + 2 counters
+    uint32_t sampleCount = 0;
+
+    // stats / timing
+    unsigned long long *dStats = nullptr; // 8 x u64
+    uint32_t *dErrorFlag = nullptr;
+    bool countersOn = false;
+    bool timingOn = false;
+    double buildMs = 0, renderMs = 0;
+    std::map<std::string, RtKernelTimer> timers;
+    std::vector<RtPendingEvent> pending;
+    std::vector<hipEvent_t> eventPool;
+};
+
+// ---- helpers shared by the translation units -------------------------------
+int rt_fail(RtContext *ctx, int code, const char *fmt, ...);
+#define RT_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e__ = (call);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return rt_fail((ctx), e__ == hipErrorOutOfMemory ? RT_E_NOMEM : RT_E_DEVICE,           \
+                           "%s failed: %s", #call, hipGetErrorString(e__));                        \
+    } while (0)
+
+void rt_timer_begin(RtContext *ctx, const char *name);
+void rt_timer_end(RtContext *ctx);
+void rt_timer_resolve(RtContext *ctx);
+
+// build.hip
+int rt_build_impl(RtContext *ctx);
+int rt_readback_bvh_impl(RtContext *ctx, uint32_t *morton, uint32_t *sortedIdx, RtAABB *triAABB, RtTriangle *tris,
+                         RtInternalNode *inodes, RtLeafNode *leaves, RtAABB *bvhData);
+void rt_free_build(RtContext *ctx);
+
+// render.hip
+RtSceneView rt_scene_view(RtContext *ctx);
+int rt_alloc_render(RtContext *ctx);
+void rt_free_render(RtContext *ctx);
+int rt_dispatch_impl(RtContext *ctx);
+int rt_shadowmap_impl(RtContext *ctx);
+int rt_accumulate_impl(RtContext *ctx, uint32_t samplePerPixel, int useShadowMap);
+int rt_trace_device_impl(RtContext *ctx, const float4 *o, const float4 *d, uint32_t n, RtHitRec *hits);
+int rt_expand_local_impl(RtContext *ctx, const float4 *local, float4 *full);
+int rt_pack_rays_impl(RtContext *ctx, const float *o3, const float *d3, uint32_t n, float4 *o4, float4 *d4);
+int rt_debug_eval_impl(RtContext *ctx, int which, const float *dx, const float *dy, uint32_t n, float *dout);
+int rt_hits_to_host_impl(RtContext *ctx, const RtHitRec *hits, uint32_t n, float *t, uint32_t *tri, float *u, float *v);
+
+#endif

@@ -1,0 +1,260 @@
+"""GPU parity tests: the HIP library (through its C ABI) against the CPU checker
+on the same seeded inputs.  Integer / index / box outputs must be bit-exact;
+radiance must agree to per-pixel relative L2 <= 1e-3 (BASELINE north star)."""
+import numpy as np
+import pytest
+
+from raytracing_amd import scenes, wire
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+RADIANCE_REL_L2 = 1e-3
+
+
+def _specials():
+    return np.array([0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 1e-30, 1e30, 3.14159265, 1e6, -1e6, np.inf, -np.inf, np.nan,
+                     4294967296.0, 4294967040.0, 2147483648.0, 0.99999994, 1.0000001], np.float32)
+
+
+def test_device_math_is_bit_identical_to_host(core, oracle):
+    rs = np.random.Generator(np.random.PCG64(11))
+    x_big = np.concatenate([rs.uniform(-3e5, 3e5, 200000), rs.uniform(-10, 10, 100000), _specials()]).astype(np.float32)
+    x_unit = np.concatenate([rs.uniform(-1.0, 1.0, 200000), _specials()]).astype(np.float32)
+    x_pos = np.concatenate([rs.uniform(0, 4, 200000), _specials()]).astype(np.float32)
+    y_pow = np.concatenate([rs.uniform(-4, 8, 200000), _specials()[::-1]]).astype(np.float32)
+    for which, x, y in ((0, x_big, None), (1, x_big, None), (2, x_unit, None), (3, x_pos, y_pow), (4, x_unit, None),
+                        (5, x_unit, None), (6, x_big * np.float32(1e4), None)):
+        want = oracle.math(which, x, y)
+        got = core.debug_eval(which, x, y)
+        H.assert_bits_equal(got, want, f"rt_math function {which}")
+
+
+@pytest.mark.parametrize("px,py,seed", [(0, 0, 0.25), (1, 1, 0.25), (7, 3, 0.25), (1919, 1079, 0.25), (3839, 2159, 0.73)])
+def test_device_rand_stream(core, oracle, px, py, seed):
+    want, _ = oracle.rand_sequence(px, py, seed, 128)
+    got = core.debug_eval(7, np.array([px, py], np.float32), np.array([seed], np.float32), n=128)
+    H.assert_bits_equal(got, want, "Rand() stream")
+
+
+def _scene(name):
+    if name == "cornell":
+        return scenes.cornell_box(64, 64, sphere_segments=32)
+    if name == "soup20k":
+        return scenes.triangle_soup(20000, seed=5)
+    if name == "dups":
+        return H.duplicate_heavy_scene()
+    if name.startswith("tiny"):
+        return scenes.triangle_soup(int(name[4:]), seed=9)
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["cornell", "soup20k", "dups", "tiny1", "tiny2", "tiny3", "tiny5", "tiny4097"])
+def test_bvh_build_bit_exact(core, oracle, name):
+    sc = _scene(name)
+    want = oracle.Oracle(sc).build().readback_bvh()
+    core.upload(sc)
+    core.bvh_build()
+    got = core.readback_bvh()
+    for key in ("morton_unsorted", "morton_sorted_raw", "morton", "sorted_index", "tri_aabb", "triangles", "internal",
+                "leaves", "bvh_data"):
+        H.assert_bits_equal(got[key], want[key], f"{name}:{key}")
+
+
+def test_empty_scene(core):
+    sc = scenes.triangle_soup(4, seed=1)
+    core.scene_upload(sc.vertices[:0], sc.indices[:0], sc.material_index[:0], sc.shadow_index[:0])
+    core.materials_upload(sc.materials)
+    core.bvh_build()
+    o, d = H.random_rays(64, 1, -1, 1)
+    r = core.trace_rays(o, d)
+    assert np.isinf(r["t"]).all() and (r["triangle"] == 0xFFFFFFFF).all()
+
+
+@pytest.mark.parametrize("name", ["cornell", "soup20k", "dups", "tiny1", "tiny2"])
+def test_first_hit_bit_exact(core, oracle, name):
+    sc = _scene(name)
+    orc = oracle.Oracle(sc).build()
+    core.upload(sc)
+    core.bvh_build()
+    if name == "cornell":
+        o1, d1 = H.camera_rays(sc.params, 96)
+        o2, d2 = H.random_rays(20000, 2, -9, 14)
+    else:
+        o1, d1 = H.random_rays(20000, 3, -110, 110)
+        o2, d2 = scenes.stress_rays(20000, seed=4)
+    # axis-parallel and degenerate directions exercise the inf / NaN slab cases
+    o3 = np.tile(np.array([[0.5, 3.0, -20.0]], np.float32), (6, 1))
+    d3 = np.array([[0, 0, 1], [1, 0, 0], [0, -1, 0], [0, 0, 0], [np.nan, 0, 1], [0, 1e-30, 1]], np.float32)
+    o = np.concatenate([o1, o2, o3])
+    d = np.concatenate([d1, d2, d3])
+    core.enable_counters(True)
+    core.reset_stats()
+    got = core.trace_rays(o, d)
+    st = core.stats()
+    core.enable_counters(False)
+    want = orc.trace(o, d)
+    H.assert_bits_equal(got["triangle"], want["triangle"], "first-hit triangle id")
+    H.assert_bits_equal(got["t"], want["t"], "hit distance")
+    hit = want["triangle"] != 0xFFFFFFFF
+    H.assert_bits_equal(got["u"][hit], want["u"][hit], "barycentric u")
+    H.assert_bits_equal(got["v"][hit], want["v"][hit], "barycentric v")
+    for k in ("rays", "internalVisits", "leafVisits", "triTests", "hits"):
+        assert st[k] == want["counters"][k], f"counter {k}: gpu {st[k]} vs oracle {want['counters'][k]}"
+    if name in ("cornell", "soup20k"):
+        assert hit.sum() > 100
+
+
+@pytest.mark.parametrize("sampling", [wire.SAMPLING_MIS, wire.SAMPLING_BSDF, wire.SAMPLING_LIGHT, wire.SAMPLING_COSINE,
+                                      wire.SAMPLING_UNIFORM])
+def test_cornell_radiance(core, oracle, sampling):
+    sc = scenes.cornell_box(96, 64, sphere_segments=24, sampling=sampling)
+    seeds = scenes.frame_seeds(4, seed=1)
+    orc = oracle.Oracle(sc).build()
+    want = oracle.render_frames(orc, sc.params, seeds)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(sc.params)
+    core.set_dirty()
+    core.render_frames(seeds)
+    got = core.readback(wire.IMAGE_CONVERGED)
+    rel = H.relative_l2(got, want)
+    assert np.isfinite(got[..., :3]).all()
+    assert rel.max() <= RADIANCE_REL_L2, f"max per-pixel relative L2 {rel.max():.3e} (mean {rel.mean():.3e})"
+    H.assert_bits_equal(got[..., 3], want[..., 3], "accumulated alpha")
+    assert want[..., :3].mean() > 0.01
+
+
+def test_single_frame_matches_oracle_bitwise(core, oracle):
+    """One CSMain dispatch (1 spp): same arithmetic on both sides -> same bits."""
+    sc = scenes.cornell_box(80, 48, sphere_segments=24)
+    orc = oracle.Oracle(sc).build()
+    p = sc.params.copy()
+    p.seed = 0.625
+    want = orc.render(p)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(p)
+    core.dispatch()
+    got = core.readback(wire.IMAGE_RT)
+    H.assert_bits_equal(got, want, "1-spp frame")
+
+
+def test_two_sphere_and_area_lights(core, oracle):
+    sc = scenes.cornell_box(64, 48, sphere_segments=16)
+    sc.sphere_lights = np.array([scenes.sphere_light((-3, 11, -2), 0.5, 2.0), scenes.sphere_light((4, 12, 1), 0.5, 1.0)],
+                                wire.SPHERE_LIGHT)
+    seeds = scenes.frame_seeds(3, seed=2)
+    orc = oracle.Oracle(sc).build()
+    want = oracle.render_frames(orc, sc.params, seeds)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(sc.params)
+    core.set_dirty()
+    core.render_frames(seeds)
+    got = core.readback(wire.IMAGE_CONVERGED)
+    assert H.relative_l2(got, want).max() <= RADIANCE_REL_L2
+
+
+def test_shadowmap_dof_and_matte(core, oracle):
+    sc = scenes.car_standin(64, 48, detail=0.02)
+    seeds = scenes.frame_seeds(2, seed=3)
+    orc = oracle.Oracle(sc).build()
+    want = oracle.render_frames(orc, sc.params, seeds, use_shadow=True)
+    p = sc.params.copy()
+    p.seed = float(seeds[1])
+    want_sm = orc.shadowmap(p)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(sc.params)
+    core.set_dirty()
+    core.render_frames(seeds)
+    got = core.readback(wire.IMAGE_CONVERGED)
+    got_sm = core.readback(wire.IMAGE_SHADOWMAP)
+    H.assert_bits_equal(got_sm, want_sm, "shadow map")
+    assert H.relative_l2(got, want).max() <= RADIANCE_REL_L2
+    assert (want_sm[..., 0] < 1).any(), "scene should contain shadowed pixels"
+
+
+def test_manual_dispatch_accumulate_equals_render_frames(core):
+    sc = scenes.cornell_box(64, 64, sphere_segments=16)
+    seeds = scenes.frame_seeds(3, seed=5)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(sc.params)
+    core.set_dirty()
+    core.render_frames(seeds)
+    a = core.readback(wire.IMAGE_CONVERGED)
+    assert core.sample_count == 3
+    p = sc.params.copy()
+    for k, s in enumerate(seeds):
+        p.seed = float(s)
+        core.set_params(p)
+        core.dispatch()
+        core.accumulate(k, False)
+    b = core.readback(wire.IMAGE_CONVERGED)
+    H.assert_bits_equal(a, b, "render_frames vs dispatch+accumulate")
+
+
+def test_tiles_union_is_bit_identical_to_whole_frame(core):
+    sc = scenes.cornell_box(200, 136, sphere_segments=16)     # not a multiple of the tile size
+    seeds = scenes.frame_seeds(2, seed=6)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(sc.params)
+    core.set_dirty()
+    core.render_frames(seeds)
+    whole = core.readback(wire.IMAGE_CONVERGED)
+    union = np.zeros_like(whole)
+    covered = np.zeros(whole.shape[:2], bool)
+    for rank in range(3):
+        p = sc.params.copy()
+        p.tileRank, p.tileCount, p.tileSize = rank, 3, 32
+        core.set_params(p)
+        core.set_dirty()
+        core.render_frames(seeds)
+        part = core.readback(wire.IMAGE_CONVERGED)
+        pm = core.local_pixel_map()
+        pm = pm[pm != 0xFFFFFFFF]
+        mask = np.zeros(whole.shape[0] * whole.shape[1], bool)
+        mask[pm] = True
+        mask = mask.reshape(whole.shape[:2])
+        assert not (covered & mask).any()
+        covered |= mask
+        union[mask] = part[mask]
+        assert (part[~mask] == 0).all()
+    assert covered.all()
+    H.assert_bits_equal(union, whole, "tile union")
+
+
+def test_resume_from_uploaded_accumulator(core):
+    sc = scenes.cornell_box(64, 64, sphere_segments=16)
+    seeds = scenes.frame_seeds(4, seed=8)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(sc.params)
+    core.set_dirty()
+    core.render_frames(seeds)
+    full = core.readback(wire.IMAGE_CONVERGED)
+    core.set_dirty()
+    core.render_frames(seeds[:2])
+    half = core.readback(wire.IMAGE_CONVERGED)
+    core.set_dirty()
+    core.upload_converged(half, 2)
+    core.render_frames(seeds[2:])
+    H.assert_bits_equal(core.readback(wire.IMAGE_CONVERGED), full, "resumed accumulation")
+
+
+def test_error_codes(core):
+    from raytracing_amd.native import RtError
+    sc = scenes.triangle_soup(8, seed=1)
+    bad = sc.indices.copy()
+    bad[3] = 10 ** 6
+    with pytest.raises(RtError) as e:
+        core.scene_upload(sc.vertices, bad, sc.material_index, sc.shadow_index)
+    assert e.value.code == -1 and "out of range" in str(e.value)
+    core.upload(sc)
+    with pytest.raises(RtError) as e:
+        core.set_params(sc.params)
+        core.dispatch()                       # scene uploaded but not built
+    assert e.value.code == -4
