@@ -119,12 +119,15 @@ int rt_create(int device_id, RtContext **out_ctx)
     memset(&ctx->rootBox, 0, sizeof ctx->rootBox);
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&ctx->dStats, 8 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc((void **)&ctx->dErrorFlag, 4) != hipSuccess) {
+        hipMalloc((void **)&ctx->dErrorFlag, 4) != hipSuccess || hipMalloc((void **)&ctx->dQCount, 32 * 4) != hipSuccess) {
         delete ctx;
         return RT_E_DEVICE;
     }
     (void)hipMemset(ctx->dStats, 0, 8 * sizeof(unsigned long long));
     (void)hipMemset(ctx->dErrorFlag, 0, 4);
+    (void)hipMemset(ctx->dQCount, 0, 32 * 4);
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) ctx->numCU = cus;
     *out_ctx = ctx;
     return RT_OK;
 }
@@ -139,7 +142,7 @@ int rt_destroy(RtContext *ctx)
     rt_free_build(ctx);
     rt_free_render(ctx);
     void *ptrs[] = {ctx->dVerts, ctx->dIdx, ctx->dMatIdx, ctx->dShadow, ctx->dMats, ctx->dSphere, ctx->dArea,
-                    ctx->dDisc, ctx->dCube, ctx->dStats, ctx->dErrorFlag};
+                    ctx->dDisc, ctx->dCube, ctx->dStats, ctx->dErrorFlag, ctx->dQCount};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -3,8 +3,8 @@
 // Reference path being replaced (same results on the same inputs and seeds):
 //   Assets/Shaders/BVH/BVHRayTracing.cginc:27-133        traversal (rt_traverse)
 //   Assets/Shaders/RayTracing/BruteForceRayTracing.cginc:166-204  Moller-Trumbore
-//   Assets/Shaders/RayTracing/RayTracing.compute:44-91   CSMain  -> k_generate / k_extend / k_shade
-//   Assets/Shaders/RayTracing/RayTracing.compute:96-131  ShadowMap -> k_shadowmap
+//   Assets/Shaders/RayTracing/RayTracing.compute:44-91   CSMain  -> k_generate / k_traverse<QueueSrc> / k_shade
+//   Assets/Shaders/RayTracing/RayTracing.compute:96-131  ShadowMap -> k_sm_generate / k_sm_setup / k_traverse<ShadowSrc> / k_sm_resolve
 //   Assets/Shaders/RayTracing/AddShader.shader:47-79     accumulate -> k_accumulate
 //
 // The reference runs one thread per pixel through all 8 bounces.  Here a frame
@@ -14,113 +14,7 @@
 #include "rt_internal.h"
 #include "rt_shade.h"
 
-#define TRV_THREADS 256
-
-// ------------------------------------------------------------------ traversal
-// Slab test exactly as RayBoxIntersection: true divisions, min/max returning
-// the non-NaN operand (v_min_f32 / v_max_f32 in IEEE mode).
-__device__ __forceinline__ bool box_hit(float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz,
-                                        const rt_f3 o, const rt_f3 d)
-{
-    const float t1x = (bminx - o.x) / d.x, t1y = (bminy - o.y) / d.y, t1z = (bminz - o.z) / d.z;
-    const float t2x = (bmaxx - o.x) / d.x, t2y = (bmaxy - o.y) / d.y, t2z = (bmaxz - o.z) / d.z;
-    const float tmin = __builtin_fmaxf(__builtin_fminf(t1x, t2x),
-                                       __builtin_fmaxf(__builtin_fminf(t1y, t2y), __builtin_fminf(t1z, t2z)));
-    const float tmax = __builtin_fminf(__builtin_fmaxf(t1x, t2x),
-                                       __builtin_fminf(__builtin_fmaxf(t1y, t2y), __builtin_fmaxf(t1z, t2z)));
-    return tmax > tmin && tmax > 0.0f;
-}
-
-__device__ __forceinline__ void tri_test(const RtSceneView &sv, uint32_t leaf, const rt_f3 o, const rt_f3 d, RtHitRec &h)
-{
-    const float4 *p = (const float4 *)(sv.leafTri + leaf);
-    const float4 a = p[0], b = p[1], c = p[2];
-    const rt_f3 v0 = rt_mk3(a.x, a.y, a.z), e1 = rt_mk3(a.w, b.x, b.y), e2 = rt_mk3(b.z, b.w, c.x);
-    const rt_f3 pvec = rt_cross3(d, e2);
-    const float det = rt_dot3(e1, pvec);
-    if (det < RT_EPSILON) return;
-    const float inv_det = 1.0f / det;
-    const rt_f3 tvec = rt_sub3(o, v0);
-    const float u = rt_dot3(tvec, pvec) * inv_det;
-    if (u < 0.0f || u > 1.0f) return;
-    const rt_f3 qvec = rt_cross3(tvec, e1);
-    const float v = rt_dot3(d, qvec) * inv_det;
-    if (v < 0.0f || u + v > 1.0f) return;
-    const float t = rt_dot3(e2, qvec) * inv_det;
-    if (t > 0.0f && t < h.t) {
-        h.t = t;
-        h.u = u;
-        h.v = v;
-        h.leaf = leaf;
-    }
-}
-
-// Depth-first walk in the reference's visiting order: at a node, the left
-// then the right LEAF child are tested at once; then the right subtree is
-// walked before the left one (the reference pushes left, then right, and pops
-// right first).  No distance pruning: the closest hit wins with strict '<', so
-// on equal distances the first-visited triangle is kept.
-// stk = this lane's column of the LDS stack, entries `stride` words apart.
-template <bool COUNT>
-__device__ __forceinline__ RtHitRec rt_traverse(const RtSceneView &sv, const rt_f3 o, const rt_f3 d, uint32_t *stk,
-                                                const uint32_t stride, uint32_t cnt[3])
-{
-    RtHitRec h;
-    h.t = rt_inf();
-    h.u = 0.0f;
-    h.v = 0.0f;
-    h.leaf = RT_INVALID;
-    if (sv.nTriangles == 0) return h;
-    if (COUNT) cnt[0]++;
-    const RtAABB &rb = sv.rootBox;
-    if (sv.nTriangles < 2 || !box_hit(rb.min[0], rb.min[1], rb.min[2], rb.max[0], rb.max[1], rb.max[2], o, d)) return h;
-    uint32_t node = 0;
-    uint32_t sp = 0;
-    for (;;) {
-        const float4 *np = (const float4 *)(sv.nodes + node);
-        const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-        const uint32_t l = __float_as_uint(q3.x), r = __float_as_uint(q3.y);
-        const bool lLeaf = (l & RT_LEAF_BIT) != 0, rLeaf = (r & RT_LEAF_BIT) != 0;
-        const bool hitL = box_hit(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, d);
-        const bool hitR = box_hit(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, d);
-        if (COUNT) {
-            cnt[0] += (lLeaf ? 0u : 1u) + (rLeaf ? 0u : 1u);
-            cnt[1] += (lLeaf ? 1u : 0u) + (rLeaf ? 1u : 0u);
-            cnt[2] += ((lLeaf && hitL) ? 1u : 0u) + ((rLeaf && hitR) ? 1u : 0u);
-        }
-        if (lLeaf && hitL) tri_test(sv, l & ~RT_LEAF_BIT, o, d, h);
-        if (rLeaf && hitR) tri_test(sv, r & ~RT_LEAF_BIT, o, d, h);
-        const bool goL = !lLeaf && hitL, goR = !rLeaf && hitR;
-        if (goR) {
-            if (goL) {
-                if (sp >= RT_STACK_DEPTH) { *sv.errorFlag = 1u; break; }
-                stk[sp * stride] = l;
-                sp++;
-            }
-            node = r;
-        } else if (goL) {
-            node = l;
-        } else {
-            if (sp == 0) break;
-            sp--;
-            node = stk[sp * stride];
-        }
-    }
-    return h;
-}
-
-__device__ __forceinline__ void flush_counters(const RtSceneView &sv, uint32_t rays, const uint32_t cnt[3], uint32_t hits)
-{
-    // wave-level reduction, then one atomic per wave per counter
-    uint32_t v[5] = {rays, cnt[0], cnt[1], cnt[2], hits};
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        uint32_t x = v[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-        if ((threadIdx.x & 63u) == 0 && x) atomicAdd(&sv.stats[k], (unsigned long long)x);
-    }
-}
+#include "rt_traverse.h"
 
 // wave64 ballot + prefix-count compaction: appends `slot` of every lane with
 // keep == true to queue[], one atomic per wave.
@@ -136,24 +30,79 @@ __device__ __forceinline__ void queue_push(bool keep, uint32_t slot, uint32_t *_
     if (keep) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = slot;
 }
 
-// ------------------------------------------------------------------ first-hit query kernel
-template <bool COUNT>
-__global__ __launch_bounds__(TRV_THREADS) void k_trace(RtSceneView sv, const float4 *__restrict__ org,
-                                                        const float4 *__restrict__ dir, uint32_t n, RtHitRec *__restrict__ hits)
-{
-    __shared__ uint32_t stack[RT_STACK_DEPTH * TRV_THREADS];
-    const uint32_t i = blockIdx.x * TRV_THREADS + threadIdx.x;
-    uint32_t cnt[3] = {0, 0, 0};
-    uint32_t rays = 0, nh = 0;
-    if (i < n) {
+// ------------------------------------------------------------------ ray sources for traverse_rays
+struct ArraySrc {            // caller rays (rt_trace_rays)
+    const float4 *org, *dir;
+    uint32_t n;
+    RtHitRec *hits;
+    __device__ __forceinline__ uint32_t count() const { return n; }
+    __device__ __forceinline__ void load(uint32_t i, rt_f3 &o, rt_f3 &d) const
+    {
         const float4 o4 = org[i], d4 = dir[i];
-        const RtHitRec h = rt_traverse<COUNT>(sv, rt_mk3(o4.x, o4.y, o4.z), rt_mk3(d4.x, d4.y, d4.z), stack + threadIdx.x,
-                                              TRV_THREADS, cnt);
-        hits[i] = h;
-        rays = 1;
-        nh = h.leaf != RT_INVALID;
+        o = rt_mk3(o4.x, o4.y, o4.z);
+        d = rt_mk3(d4.x, d4.y, d4.z);
     }
-    if (COUNT) flush_counters(sv, rays, cnt, nh);
+    __device__ __forceinline__ void store(uint32_t i, const RtHitRec &h) const { hits[i] = h; }
+};
+
+struct QueueSrc {            // live paths of one bounce
+    const uint32_t *queue, *qcount;
+    const float4 *po, *pd;
+    RtHitRec *hit;
+    __device__ __forceinline__ uint32_t count() const { return *qcount; }
+    __device__ __forceinline__ void load(uint32_t i, rt_f3 &o, rt_f3 &d) const
+    {
+        const uint32_t slot = queue[i];
+        const float4 o4 = po[slot], d4 = pd[slot];
+        o = rt_mk3(o4.x, o4.y, o4.z);
+        d = rt_mk3(d4.x, d4.y, d4.z);
+    }
+    __device__ __forceinline__ void store(uint32_t i, const RtHitRec &h) const { hit[queue[i]] = h; }
+};
+
+// The 16 soft-shadow rays of every shaded pixel (Shadow.cginc:95-111): ray
+// i = (pixel i/16, disk sample i%16); result = "closest hit casts a shadow".
+__constant__ float c_blue_noise[16][2] = {   // first 16 entries of BLUE_NOISE_IN_DISK (Shadow.cginc:7-72)
+    {0.478712f, 0.875764f},  {-0.337956f, -0.793959f}, {-0.955259f, -0.028164f}, {0.864527f, 0.325689f},
+    {0.209342f, -0.395657f}, {-0.106779f, 0.672585f},  {0.156213f, 0.235113f},   {-0.413644f, -0.082856f},
+    {-0.415667f, 0.323909f}, {0.141896f, -0.939980f},  {0.954932f, -0.182516f},  {-0.766184f, 0.410799f},
+    {-0.434912f, -0.458845f}, {0.415242f, -0.078724f}, {0.728335f, -0.491777f},  {-0.058086f, -0.066401f}};
+
+struct ShadowSrc {
+    const uint32_t *smq, *smqCount;
+    const float4 *rec;         // per slot: (origin.xyz, cosTheta), (sinTheta, ., ., .)
+    uint8_t *flags;            // per slot x 16
+    const RtLeafShade *leafShade;
+    rt_f3 lightDir, lightTangent, lightBitangent;
+    float lightRadius;
+    __device__ __forceinline__ uint32_t count() const { return *smqCount * 16u; }
+    __device__ __forceinline__ void load(uint32_t i, rt_f3 &o, rt_f3 &d) const
+    {
+        const uint32_t slot = smq[i >> 4], k = i & 15u;
+        const float4 a = rec[slot * 2], b = rec[slot * 2 + 1];
+        const float cosTheta = a.w, sinTheta = b.x;
+        const float sx = c_blue_noise[k][0], sy = c_blue_noise[k][1];
+        float dx = sx * cosTheta - sy * sinTheta;
+        float dy = sx * sinTheta + sy * cosTheta;
+        dx *= lightRadius;
+        dy *= lightRadius;
+        o = rt_mk3(a.x, a.y, a.z);
+        d = rt_normalize3(rt_add3(rt_add3(lightDir, rt_scale3(lightTangent, dx)), rt_scale3(lightBitangent, dy)));
+    }
+    __device__ __forceinline__ void store(uint32_t i, const RtHitRec &h) const
+    {
+        const uint32_t slot = smq[i >> 4], k = i & 15u;
+        uint8_t f = 0;
+        if (h.leaf != RT_INVALID) f = __float_as_int(((const float4 *)(leafShade + h.leaf))[2].z) > 0 ? 1 : 0;
+        flags[(size_t)slot * 16 + k] = f;
+    }
+};
+
+template <bool COUNT, class Src>
+__global__ __launch_bounds__(TRV_THREADS) void k_traverse(RtSceneView sv, Src src, uint32_t *__restrict__ fetchCounter)
+{
+    __shared__ uint32_t lds[TRV_LDS_WORDS];
+    traverse_rays<COUNT>(sv, src, fetchCounter, lds);
 }
 
 __global__ void k_unpack_hits(RtSceneView sv, const RtHitRec *__restrict__ hits, uint32_t n, float *t, uint32_t *tri,
@@ -201,30 +150,6 @@ __global__ __launch_bounds__(256) void k_generate(RtTileMap tm, RtParams P, floa
         rng[slot] = make_uint2(r.state, __float_as_uint(r.seed));
     }
     queue_push(active, slot, queue, qcount);
-}
-
-// BVHRayTrace for every live path of this bounce.
-template <bool COUNT>
-__global__ __launch_bounds__(TRV_THREADS) void k_extend(RtSceneView sv, const uint32_t *__restrict__ queue,
-                                                         const uint32_t *__restrict__ qcount, const float4 *__restrict__ po,
-                                                         const float4 *__restrict__ pd, RtHitRec *__restrict__ hit)
-{
-    __shared__ uint32_t stack[RT_STACK_DEPTH * TRV_THREADS];
-    const uint32_t i = blockIdx.x * TRV_THREADS + threadIdx.x;
-    const uint32_t n = *qcount;
-    if (blockIdx.x * TRV_THREADS >= n) return;
-    uint32_t cnt[3] = {0, 0, 0};
-    uint32_t rays = 0, nh = 0;
-    if (i < n) {
-        const uint32_t slot = queue[i];
-        const float4 o4 = po[slot], d4 = pd[slot];
-        const RtHitRec h = rt_traverse<COUNT>(sv, rt_mk3(o4.x, o4.y, o4.z), rt_mk3(d4.x, d4.y, d4.z), stack + threadIdx.x,
-                                              TRV_THREADS, cnt);
-        hit[slot] = h;
-        rays = 1;
-        nh = h.leaf != RT_INVALID;
-    }
-    if (COUNT) flush_counters(sv, rays, cnt, nh);
 }
 
 // Gathers what CheckTriangle copies into RayHit on an accepted hit
@@ -328,22 +253,17 @@ __global__ __launch_bounds__(256) void k_shade(RtSceneView sv, RtTileMap tm, RtP
     queue_push(alive, slot, queueOut, countOut);
 }
 
-// ------------------------------------------------------------------ ShadowMap kernel
-__constant__ float c_blue_noise[16][2] = {   // first 16 entries of BLUE_NOISE_IN_DISK (Shadow.cginc:7-72)
-    {0.478712f, 0.875764f},  {-0.337956f, -0.793959f}, {-0.955259f, -0.028164f}, {0.864527f, 0.325689f},
-    {0.209342f, -0.395657f}, {-0.106779f, 0.672585f},  {0.156213f, 0.235113f},   {-0.413644f, -0.082856f},
-    {-0.415667f, 0.323909f}, {0.141896f, -0.939980f},  {0.954932f, -0.182516f},  {-0.766184f, 0.410799f},
-    {-0.434912f, -0.458845f}, {0.415242f, -0.078724f}, {0.728335f, -0.491777f},  {-0.058086f, -0.066401f}};
-
-template <bool COUNT>
-__global__ __launch_bounds__(TRV_THREADS) void k_shadowmap(RtSceneView sv, RtTileMap tm, RtParams P, float4 *__restrict__ out)
+// ------------------------------------------------------------------ ShadowMap pass (RayTracing.compute:96-131)
+// generate (primary ray, DoF-capable) -> traverse -> setup (hit point, disk
+// rotation) -> traverse 16 shadow rays per shaded pixel -> resolve.
+__global__ __launch_bounds__(256) void k_sm_generate(RtTileMap tm, RtParams P, float4 *__restrict__ po, float4 *__restrict__ pd,
+                                                      uint2 *__restrict__ rng, float4 *__restrict__ shadowMap,
+                                                      uint32_t *__restrict__ queue, uint32_t *__restrict__ qcount)
 {
-    __shared__ uint32_t stack[RT_STACK_DEPTH * TRV_THREADS];
-    const uint32_t slot = blockIdx.x * TRV_THREADS + threadIdx.x;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t px = 0, py = 0;
     const bool active = slot < tm.nSlots && tm.slot_to_pixel(slot, &px, &py);
-    uint32_t cnt[3] = {0, 0, 0};
-    uint32_t rays = 0, nh = 0;
+    if (slot < tm.nSlots && !active) shadowMap[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (active) {
         rt_rng r;
         rt_rng_init(&r, px, py, P.seed);
@@ -353,49 +273,73 @@ __global__ __launch_bounds__(TRV_THREADS) void k_shadowmap(RtSceneView sv, RtTil
         rt_f3 o, d;
         if (P.flags & RT_FLAG_DEPTH_OF_FIELD) d_dof_camera_ray(P, r, uvx, uvy, o, d);
         else d_camera_ray(P, uvx, uvy, o, d);
-        const RtHitRec h = rt_traverse<COUNT>(sv, o, d, stack + threadIdx.x, TRV_THREADS, cnt);
-        rays++;
-        float4 res = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-        if (h.leaf != RT_INVALID) {
-            nh++;
+        po[slot] = make_float4(o.x, o.y, o.z, 0.0f);
+        pd[slot] = make_float4(d.x, d.y, d.z, 0.0f);
+        rng[slot] = make_uint2(r.state, __float_as_uint(r.seed));
+    }
+    queue_push(active, slot, queue, qcount);
+}
+
+__global__ __launch_bounds__(256) void k_sm_setup(RtSceneView sv, RtTileMap tm, RtParams P, const uint32_t *__restrict__ queue,
+                                                   const uint32_t *__restrict__ qcount, const float4 *__restrict__ po,
+                                                   const float4 *__restrict__ pd, const uint2 *__restrict__ rng,
+                                                   const RtHitRec *__restrict__ hitRec, float4 *__restrict__ rec,
+                                                   float4 *__restrict__ shadowMap, uint32_t *__restrict__ smq,
+                                                   uint32_t *__restrict__ smqCount)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = *qcount;
+    if (blockIdx.x * blockDim.x >= n) return;
+    bool shaded = false;
+    uint32_t slot = 0;
+    if (i < n) {
+        slot = queue[i];
+        const RtHitRec h = hitRec[slot];
+        if (h.leaf == RT_INVALID) {
+            shadowMap[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        } else {
+            const float4 o4 = po[slot], d4 = pd[slot];
             DHit hit;
             int castShadow;
-            load_hit(sv, h, o, d, hit, castShadow);
-            // SoftShadow (Shadow.cginc:84-113)
+            load_hit(sv, h, rt_mk3(o4.x, o4.y, o4.z), rt_mk3(d4.x, d4.y, d4.z), hit, castShadow);
             const rt_f3 origin = rt_add3(hit.position, rt_scale3(hit.normal, RT_NORMAL_BIAS));
-            const rt_f3 lightDir = rt_mk3(-P.lightParameter[0], -P.lightParameter[1], -P.lightParameter[2]);
-            const float lightRadius = P.lightParameter[3];
+            rt_rng r;
+            uint32_t px, py;
+            tm.slot_to_pixel(slot, &px, &py);
+            const uint2 rs = rng[slot];
+            r.state = rs.x;
+            r.seed = __uint_as_float(rs.y);
+            r.px = (float)px;
+            r.py = (float)py;
             const float blueNoise = rt_rand(&r);
             const float theta = blueNoise * 2.0f * RT_PI;
             const float cosTheta = rt_cos(theta);
             const float sinTheta = rt_sin(theta);
-            float shadowTerm = 0.0f;
-            const rt_f3 lightTangent = rt_normalize3(rt_cross3(lightDir, rt_mk3(0.0f, 1.0f, 0.0f)));
-            const rt_f3 lightBitangent = rt_normalize3(rt_cross3(lightTangent, lightDir));
-            for (int k = 0; k < 16; ++k) {
-                const float sx = c_blue_noise[k][0], sy = c_blue_noise[k][1];
-                float dx = sx * cosTheta - sy * sinTheta;
-                float dy = sx * sinTheta + sy * cosTheta;
-                dx *= lightRadius;
-                dy *= lightRadius;
-                const rt_f3 sd = rt_normalize3(rt_add3(rt_add3(lightDir, rt_scale3(lightTangent, dx)), rt_scale3(lightBitangent, dy)));
-                const RtHitRec sh = rt_traverse<COUNT>(sv, origin, sd, stack + threadIdx.x, TRV_THREADS, cnt);
-                rays++;
-                if (sh.leaf != RT_INVALID) {
-                    nh++;
-                    const int cast = __float_as_int(((const float4 *)(sv.leafShade + sh.leaf))[2].z);
-                    if (cast > 0) shadowTerm = rt_lerp(shadowTerm, 1.0f, 1.0f / (float)(k + 1));
-                }
-            }
-            const rt_f3 s = rt_lerp3(rt_splat3(1.0f), rt_mk3(P.shadowParameter[0], P.shadowParameter[1], P.shadowParameter[2]),
-                                     P.shadowParameter[3] * shadowTerm);
-            res = make_float4(s.x, s.y, s.z, hit.materialType == 4 ? 0.0f : 1.0f);
+            rec[slot * 2 + 0] = make_float4(origin.x, origin.y, origin.z, cosTheta);
+            rec[slot * 2 + 1] = make_float4(sinTheta, hit.materialType == 4 ? 0.0f : 1.0f, 0.0f, 0.0f);
+            shaded = true;
         }
-        out[slot] = res;
-    } else if (slot < tm.nSlots) {
-        out[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    if (COUNT) flush_counters(sv, rays, cnt, nh);
+    queue_push(shaded, slot, smq, smqCount);
+}
+
+// SoftShadow's running mean over the 16 rays, in ray order (Shadow.cginc:109-112).
+__global__ __launch_bounds__(256) void k_sm_resolve(RtParams P, const uint32_t *__restrict__ smq, const uint32_t *__restrict__ smqCount,
+                                                     const float4 *__restrict__ rec, const uint8_t *__restrict__ flags,
+                                                     float4 *__restrict__ shadowMap)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *smqCount) return;
+    const uint32_t slot = smq[i];
+    const uint4 f4 = *(const uint4 *)(flags + (size_t)slot * 16);
+    const uint32_t w[4] = {f4.x, f4.y, f4.z, f4.w};
+    float shadowTerm = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if ((w[k >> 2] >> ((k & 3) * 8)) & 0xFFu) shadowTerm = rt_lerp(shadowTerm, 1.0f, 1.0f / (float)(k + 1));
+    const rt_f3 s = rt_lerp3(rt_splat3(1.0f), rt_mk3(P.shadowParameter[0], P.shadowParameter[1], P.shadowParameter[2]),
+                             P.shadowParameter[3] * shadowTerm);
+    shadowMap[slot] = make_float4(s.x, s.y, s.z, rec[slot * 2 + 1].y);
 }
 
 // ------------------------------------------------------------------ accumulate
@@ -479,11 +423,21 @@ RtSceneView rt_scene_view(RtContext *ctx)
     return sv;
 }
 
+// Layout of the small counter block (dQCount), zeroed at the start of a frame:
+//   [0..8]  live-path counts of bounce 0..8      [9]  shaded pixels of the ShadowMap pass
+//   [16..23] ray-fetch cursors of the 8 extend launches, [24]/[25] ShadowMap primary / shadow rays, [26] rt_trace_rays
+#define CNT_SMQ 9
+#define CNT_FETCH 16
+#define CNT_FETCH_SM0 24
+#define CNT_FETCH_SM1 25
+#define CNT_FETCH_TRACE 26
+#define CNT_WORDS 32
+
 void rt_free_render(RtContext *ctx)
 {
     void **ptrs[] = {(void **)&ctx->dRt, (void **)&ctx->dConv, (void **)&ctx->dShadowMap, (void **)&ctx->dPo,
                      (void **)&ctx->dPd, (void **)&ctx->dPe, (void **)&ctx->dRng, (void **)&ctx->dHit,
-                     (void **)&ctx->dQueue[0], (void **)&ctx->dQueue[1], (void **)&ctx->dQCount};
+                     (void **)&ctx->dQueue[0], (void **)&ctx->dQueue[1], (void **)&ctx->dSmRec, (void **)&ctx->dSmFlags};
     for (void **p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -507,13 +461,29 @@ int rt_alloc_render(RtContext *ctx)
     RT_HIP(ctx, hipMalloc((void **)&ctx->dHit, m * sizeof(RtHitRec)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dQueue[0], m * sizeof(uint32_t)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dQueue[1], m * sizeof(uint32_t)));
-    RT_HIP(ctx, hipMalloc((void **)&ctx->dQCount, (RT_MAX_BOUNCE + 2) * sizeof(uint32_t)));
+    RT_HIP(ctx, hipMalloc((void **)&ctx->dSmRec, m * 2 * sizeof(float4)));
+    RT_HIP(ctx, hipMalloc((void **)&ctx->dSmFlags, m * 16));
     RT_HIP(ctx, hipMemsetAsync(ctx->dRt, 0, m * sizeof(float4), ctx->stream));
     RT_HIP(ctx, hipMemsetAsync(ctx->dConv, 0, m * sizeof(float4), ctx->stream));
     RT_HIP(ctx, hipMemsetAsync(ctx->dShadowMap, 0, m * sizeof(float4), ctx->stream));
     ctx->allocSlots = n;
     ctx->sampleCount = 0;
     return RT_OK;
+}
+
+// Persistent launch: enough resident waves to fill the chip; every wave pulls
+// rays from the shared cursor until none are left.
+template <class Src>
+static void launch_traverse(RtContext *ctx, const RtSceneView &sv, const Src &src, uint32_t *fetchCounter, uint32_t maxRays,
+                            const char *name)
+{
+    uint32_t blocks = (uint32_t)ctx->numCU * 4u;
+    const uint32_t need = (maxRays + TRV_THREADS - 1) / TRV_THREADS;
+    if (need < blocks) blocks = need ? need : 1;
+    rt_timer_begin(ctx, name);
+    if (ctx->countersOn) hipLaunchKernelGGL((k_traverse<true, Src>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, src, fetchCounter);
+    else hipLaunchKernelGGL((k_traverse<false, Src>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, src, fetchCounter);
+    rt_timer_end(ctx);
 }
 
 int rt_dispatch_impl(RtContext *ctx)
@@ -523,19 +493,20 @@ int rt_dispatch_impl(RtContext *ctx)
     hipStream_t st = ctx->stream;
     const RtSceneView sv = rt_scene_view(ctx);
     const dim3 blk(256), grid((n + 255) / 256);
-    RT_HIP(ctx, hipMemsetAsync(ctx->dQCount, 0, (RT_MAX_BOUNCE + 2) * sizeof(uint32_t), st));
+    RT_HIP(ctx, hipMemsetAsync(ctx->dQCount, 0, CNT_WORDS * sizeof(uint32_t), st));
     rt_timer_begin(ctx, "k_generate");
     hipLaunchKernelGGL(k_generate, grid, blk, 0, st, ctx->tile, ctx->params, ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt,
                        ctx->dRng, ctx->dQueue[0], ctx->dQCount);
     rt_timer_end(ctx);
     for (int b = 0; b < RT_MAX_BOUNCE; ++b) {
         uint32_t *qin = ctx->dQueue[b & 1], *qout = ctx->dQueue[(b + 1) & 1];
-        rt_timer_begin(ctx, "k_extend");
-        if (ctx->countersOn)
-            hipLaunchKernelGGL((k_extend<true>), grid, dim3(TRV_THREADS), 0, st, sv, qin, ctx->dQCount + b, ctx->dPo, ctx->dPd, ctx->dHit);
-        else
-            hipLaunchKernelGGL((k_extend<false>), grid, dim3(TRV_THREADS), 0, st, sv, qin, ctx->dQCount + b, ctx->dPo, ctx->dPd, ctx->dHit);
-        rt_timer_end(ctx);
+        QueueSrc src;
+        src.queue = qin;
+        src.qcount = ctx->dQCount + b;
+        src.po = ctx->dPo;
+        src.pd = ctx->dPd;
+        src.hit = ctx->dHit;
+        launch_traverse(ctx, sv, src, ctx->dQCount + CNT_FETCH + b, n, "k_extend");
         rt_timer_begin(ctx, "k_shade");
         hipLaunchKernelGGL(k_shade, grid, blk, 0, st, sv, ctx->tile, ctx->params, b, qin, ctx->dQCount + b, qout, ctx->dQCount + b + 1,
                            ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
@@ -549,13 +520,44 @@ int rt_shadowmap_impl(RtContext *ctx)
 {
     const uint32_t n = ctx->tile.nSlots;
     if (n == 0) return RT_OK;
+    hipStream_t st = ctx->stream;
     const RtSceneView sv = rt_scene_view(ctx);
-    const dim3 grid((n + TRV_THREADS - 1) / TRV_THREADS);
-    rt_timer_begin(ctx, "k_shadowmap");
-    if (ctx->countersOn)
-        hipLaunchKernelGGL((k_shadowmap<true>), grid, dim3(TRV_THREADS), 0, ctx->stream, sv, ctx->tile, ctx->params, ctx->dShadowMap);
-    else
-        hipLaunchKernelGGL((k_shadowmap<false>), grid, dim3(TRV_THREADS), 0, ctx->stream, sv, ctx->tile, ctx->params, ctx->dShadowMap);
+    const RtParams &P = ctx->params;
+    const dim3 blk(256), grid((n + 255) / 256);
+    uint32_t *cnt = ctx->dQCount;
+    // the path-state buffers of CSMain are free again at this point and are reused
+    RT_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t), st));
+    RT_HIP(ctx, hipMemsetAsync(cnt + CNT_SMQ, 0, sizeof(uint32_t), st));
+    RT_HIP(ctx, hipMemsetAsync(cnt + CNT_FETCH_SM0, 0, 2 * sizeof(uint32_t), st));
+    rt_timer_begin(ctx, "k_sm_generate");
+    hipLaunchKernelGGL(k_sm_generate, grid, blk, 0, st, ctx->tile, P, ctx->dPo, ctx->dPd, ctx->dRng, ctx->dShadowMap,
+                       ctx->dQueue[0], cnt);
+    rt_timer_end(ctx);
+    QueueSrc prim;
+    prim.queue = ctx->dQueue[0];
+    prim.qcount = cnt;
+    prim.po = ctx->dPo;
+    prim.pd = ctx->dPd;
+    prim.hit = ctx->dHit;
+    launch_traverse(ctx, sv, prim, cnt + CNT_FETCH_SM0, n, "k_extend");
+    rt_timer_begin(ctx, "k_sm_setup");
+    hipLaunchKernelGGL(k_sm_setup, grid, blk, 0, st, sv, ctx->tile, P, ctx->dQueue[0], cnt, ctx->dPo, ctx->dPd, ctx->dRng, ctx->dHit,
+                       ctx->dSmRec, ctx->dShadowMap, ctx->dQueue[1], cnt + CNT_SMQ);
+    rt_timer_end(ctx);
+    ShadowSrc sh;
+    sh.smq = ctx->dQueue[1];
+    sh.smqCount = cnt + CNT_SMQ;
+    sh.rec = ctx->dSmRec;
+    sh.flags = ctx->dSmFlags;
+    sh.leafShade = ctx->dLeafShade;
+    // Shadow.cginc:92-93, evaluated once on the host with the same IEEE float operations
+    sh.lightDir = rt_mk3(-P.lightParameter[0], -P.lightParameter[1], -P.lightParameter[2]);
+    sh.lightTangent = rt_normalize3(rt_cross3(sh.lightDir, rt_mk3(0.0f, 1.0f, 0.0f)));
+    sh.lightBitangent = rt_normalize3(rt_cross3(sh.lightTangent, sh.lightDir));
+    sh.lightRadius = P.lightParameter[3];
+    launch_traverse(ctx, sv, sh, cnt + CNT_FETCH_SM1, n * 16u, "k_shadow_rays");
+    rt_timer_begin(ctx, "k_sm_resolve");
+    hipLaunchKernelGGL(k_sm_resolve, grid, blk, 0, st, P, ctx->dQueue[1], cnt + CNT_SMQ, ctx->dSmRec, ctx->dSmFlags, ctx->dShadowMap);
     rt_timer_end(ctx);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
@@ -577,11 +579,13 @@ int rt_trace_device_impl(RtContext *ctx, const float4 *o, const float4 *d, uint3
 {
     if (n == 0) return RT_OK;
     const RtSceneView sv = rt_scene_view(ctx);
-    const dim3 grid((n + TRV_THREADS - 1) / TRV_THREADS);
-    rt_timer_begin(ctx, "k_trace");
-    if (ctx->countersOn) hipLaunchKernelGGL((k_trace<true>), grid, dim3(TRV_THREADS), 0, ctx->stream, sv, o, d, n, hits);
-    else hipLaunchKernelGGL((k_trace<false>), grid, dim3(TRV_THREADS), 0, ctx->stream, sv, o, d, n, hits);
-    rt_timer_end(ctx);
+    RT_HIP(ctx, hipMemsetAsync(ctx->dQCount + CNT_FETCH_TRACE, 0, sizeof(uint32_t), ctx->stream));
+    ArraySrc src;
+    src.org = o;
+    src.dir = d;
+    src.n = n;
+    src.hits = hits;
+    launch_traverse(ctx, sv, src, ctx->dQCount + CNT_FETCH_TRACE, n, "k_trace");
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }

@@ -147,7 +147,10 @@ struct RtContext {
     uint2 *dRng = nullptr;
     RtHitRec *dHit = nullptr;
     uint32_t *dQueue[2] = {nullptr, nullptr};
-    uint32_t *dQCount = nullptr;          // RT_MAX_BOUNCE + 2 counters
+    uint32_t *dQCount = nullptr;          // 32-word counter block, owned by the context
+    float4 *dSmRec = nullptr;             // ShadowMap pass: 2 x float4 per slot
+    uint8_t *dSmFlags = nullptr;          // ShadowMap pass: 16 results per slot
+    int numCU = 256;
     uint32_t sampleCount = 0;
 
     // stats / timing

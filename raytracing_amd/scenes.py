@@ -446,31 +446,37 @@ def car_standin(width=1920, height=1080, detail=1.0, sampling=wire.SAMPLING_MIS,
                                   float(0.2 + 0.7 * rng.next_float())))
     ground = material_data((0.5, 0.5, 0.5, 1), 0, 0.5, material_type=4)
     s = 0.7071068
-    b.add(quad_mesh(), ground, (0, 0, 0), (s, 0, 0, s), (80, 80, 1), cast_shadow=False)
+    S = 0.35                    # world scale: the focal plane (focalLength 2.0) passes through the car
+    b.add(quad_mesh(), ground, (0, 0, 0), (s, 0, 0, s), (80 * S, 80 * S, 1), cast_shadow=False)
     d = max(0.05, detail)
     L = lambda n: max(8, int(n * np.sqrt(d)))
-    b.add(_displaced_ellipsoid(rng, L(420), L(210), (2.3, 0.62, 1.0), 0.015), paint, (0, 0.85, 0))      # body
-    b.add(_displaced_ellipsoid(rng, L(300), L(150), (1.15, 0.5, 0.82), 0.0), glass, (-0.25, 1.38, 0))    # cabin
+    sc3 = lambda r: tuple(S * x for x in r)
+    b.add(_displaced_ellipsoid(rng, L(420), L(210), sc3((2.3, 0.62, 1.0)), 0.015), paint, sc3((0, 0.85, 0)))      # body
+    b.add(_displaced_ellipsoid(rng, L(300), L(150), sc3((1.15, 0.5, 0.82)), 0.0), glass, sc3((-0.25, 1.38, 0)))    # cabin
     for sx in (-1.45, 1.45):
         for sz in (-0.95, 0.95):
-            b.add(_displaced_ellipsoid(rng, L(180), L(90), (0.42, 0.42, 0.16), 0.03), rubber, (sx, 0.42, sz))
-            b.add(_displaced_ellipsoid(rng, L(90), L(45), (0.25, 0.25, 0.18), 0.0), chrome, (sx, 0.42, sz))
+            b.add(_displaced_ellipsoid(rng, L(180), L(90), sc3((0.42, 0.42, 0.16)), 0.03), rubber, sc3((sx, 0.42, sz)))
+            b.add(_displaced_ellipsoid(rng, L(90), L(45), sc3((0.25, 0.25, 0.18)), 0.0), chrome, sc3((sx, 0.42, sz)))
     for sz in (-0.6, 0.6):
-        b.add(_displaced_ellipsoid(rng, L(60), L(30), (0.12, 0.1, 0.18), 0.0), lamp, (2.2, 0.85, sz))
-        b.add(_displaced_ellipsoid(rng, L(60), L(30), (0.08, 0.08, 0.2), 0.0), tail, (-2.25, 0.9, sz))
+        b.add(_displaced_ellipsoid(rng, L(60), L(30), sc3((0.12, 0.1, 0.18)), 0.0), lamp, sc3((2.2, 0.85, sz)))
+        b.add(_displaced_ellipsoid(rng, L(60), L(30), sc3((0.08, 0.08, 0.2)), 0.0), tail, sc3((-2.25, 0.9, sz)))
     for k in range(12):
         r = rng.floats(5).astype(np.float64)
-        b.add(_displaced_ellipsoid(rng, L(70), L(35), (0.1 + 0.15 * r[0], 0.05 + 0.05 * r[1], 0.1 + 0.15 * r[2]), 0.05),
-              mats[6 + k], ((r[3] - 0.5) * 4.2, 0.5 + 0.8 * r[4], (1.0 if k % 2 else -1.0) * (0.85 + 0.1 * r[0])))
-    sl = sphere_light((3, 6, -3), 0.5, 2.0)
-    sc = b.build("car", sphere_lights=np.array([sl], wire.SPHERE_LIGHT), skybox=procedural_skybox(256),
-                 notes="procedural stand-in for Car_AlfaRomeo_8C_2007 + procedural HDRI")
+        b.add(_displaced_ellipsoid(rng, L(70), L(35), sc3((0.1 + 0.15 * r[0], 0.05 + 0.05 * r[1], 0.1 + 0.15 * r[2])), 0.05),
+              mats[6 + k], sc3(((r[3] - 0.5) * 4.2, 0.5 + 0.8 * r[4], (1.0 if k % 2 else -1.0) * (0.85 + 0.1 * r[0]))))
+    sl = sphere_light(sc3((3, 6, -3)), 0.5, 2.0 * S)
+    scn = b.build("car", sphere_lights=np.array([sl], wire.SPHERE_LIGHT), skybox=procedural_skybox(256),
+                  notes="procedural stand-in for Car_AlfaRomeo_8C_2007 + procedural HDRI")
     flags = wire.FLAG_MATTE_MASK | ((wire.FLAG_DEPTH_OF_FIELD | wire.FLAG_DOF_PRIMARY) if dof else 0)
-    sc.params = make_params(width, height, (4.2, 1.9, -5.2), quat_from_euler_deg(12, -40, 0), fov=50.0,
-                            sampling=sampling, light_radius=0.2, sky_intensity=4.0, flags=flags,
-                            lens_radius=0.3 if dof else 0.0, focal_length=2.0 if dof else 1.0,
-                            shadow_intensity=0.8)
-    return sc
+    focal = 2.0
+    cam_rot = quat_from_euler_deg(14, -40, 0)
+    target = np.array(sc3((0.1, 0.8, 0)))
+    cam_pos = target - quat_rotate(cam_rot, np.array([0.0, 0.0, 1.0])) * focal
+    scn.params = make_params(width, height, tuple(cam_pos), cam_rot, fov=50.0,
+                             sampling=sampling, light_radius=0.2, sky_intensity=4.0, flags=flags,
+                             lens_radius=0.3 if dof else 0.0, focal_length=focal if dof else 1.0,
+                             shadow_intensity=0.8)
+    return scn
 
 
 def triangle_soup(n_triangles, seed=5, width=256, height=256):
