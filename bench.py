@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from raytracing_amd import native, scenes, wire  # noqa: E402
+from raytracing_amd import dist as rtdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, spec
 
@@ -42,45 +43,6 @@ def make_scene(args):
     raise SystemExit(f"unknown workload {args.workload}")
 
 
-SCENE_ARRAYS = ("vertices", "indices", "material_index", "shadow_index", "materials", "sphere_lights", "area_lights",
-                "disc_lights", "skybox")
-
-
-def broadcast_scene(sc, rank, world, device):
-    """Rank 0 owns the generated scene; every other rank receives the raw arrays
-    over RCCL (one broadcast per array, once per scene)."""
-    import torch
-    import torch.distributed as dist
-    meta = [None]
-    if rank == 0:
-        arrays = {k: getattr(sc, k) for k in SCENE_ARRAYS}
-        meta[0] = {k: (None if a is None else (a.dtype.descr if a.dtype.names else a.dtype.str, a.shape, a.nbytes))
-                   for k, a in arrays.items()}
-        meta[0]["_params"] = bytes(sc.params)
-        meta[0]["_name"] = sc.name
-    dist.broadcast_object_list(meta, src=0)
-    m = meta[0]
-    out = {}
-    for k in SCENE_ARRAYS:
-        if m[k] is None:
-            out[k] = None
-            continue
-        descr, shape, nbytes = m[k]
-        if rank == 0:
-            t = torch.from_numpy(np.frombuffer(np.ascontiguousarray(getattr(sc, k)).tobytes(), np.uint8).copy()).to(device)
-        else:
-            t = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        if nbytes:
-            dist.broadcast(t, src=0)
-        dt = np.dtype([tuple(d) for d in descr]) if isinstance(descr, list) else np.dtype(descr)
-        out[k] = np.frombuffer(t.cpu().numpy().tobytes(), dt).reshape(shape)
-    if rank == 0:
-        return sc
-    params = wire.RtParams.from_buffer_copy(m["_params"])
-    return scenes.Scene(m["_name"], out["vertices"], out["indices"], out["material_index"], out["shadow_index"],
-                        out["materials"], out["sphere_lights"], out["area_lights"], out["disc_lights"], out["skybox"], params)
-
-
 def algorithmic_bytes(st):
     """Traversal bytes by the per-unit figures of the measurement contract:
     32 B per internal box test, 28 B per leaf box test, 36 B per triangle that
@@ -92,7 +54,7 @@ def cpu_baseline(sc, args):
     """The CPU checker (oracle/) timed on the host cores on a bounded sample of
     the same workload: the same scene and sampling at reduced resolution."""
     from oracle import oracle_py
-    w, h = max(64, args.width // 8), max(36, args.height // 8)
+    w, h = max(64, args.width // 4), max(36, args.height // 4)
     p = sc.params.copy()
     p.width, p.height = w, h
     p.cameraInverseProjection[:] = scenes.inverse_projection(50.0, w / h).tolist()
@@ -101,17 +63,21 @@ def cpu_baseline(sc, args):
     seeds = scenes.frame_seeds(64, seed=1)
     rays, t0, frames = 0, time.time(), 0
     use_shadow = bool(p.flags & wire.FLAG_MATTE_MASK)
-    while frames < len(seeds) and (frames == 0 or time.time() - t0 < 12.0):
+    while frames < len(seeds) and (frames == 0 or time.time() - t0 < 15.0):
         p.seed = float(seeds[frames])
         _, cnt = orc.render(p, counters=True)
         rays += cnt["rays"]
         if use_shadow:
-            orc.shadowmap(p)
+            sm = orc.shadowmap(p)
+            # ShadowMap kernel: 1 primary ray per pixel + 16 shadow rays per pixel that hit something (alpha or shadow < 1 marks a hit)
+            hit = (sm[..., 3] > 0) | (sm[..., 0] < 1) | (sm[..., 1] < 1) | (sm[..., 2] < 1)
+            rays += w * h + 16 * int(hit.sum())
         frames += 1
     dt = time.time() - t0
-    # shadow-map rays are traced but not returned by the counter path: count them as 0 (conservative)
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": oracle_py.lib().orc_num_threads(), "kind": "port",
-            "sample": f"{sc.name} scene, {w}x{h}, {frames} frame(s) of 1 spp, CSMain rays only, {dt:.1f} s"}
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": int(oracle_py.lib().orc_num_threads()), "kind": "port",
+            "ms_per_frame_1spp_at_full_resolution": round(dt / frames * (args.width * args.height) / (w * h) * 1e3, 1),
+            "sample": f"{sc.name} scene, {w}x{h} (1/16 of the pixels), {frames} frame(s) of 1 spp incl. ShadowMap pass, "
+                      f"{dt:.1f} s; shadow rays of matte-mask pixels whose 16 rays all miss are not counted"}
 
 
 def main():
@@ -148,7 +114,7 @@ def main():
     # ---- scene: generated on rank 0, broadcast over RCCL, built on every GPU
     sc = make_scene(args) if rank == 0 else None
     if world > 1:
-        sc = broadcast_scene(sc, rank, world, device)
+        sc = rtdist.broadcast_scene(sc, device)
     core = native.RtCore(local_rank)
     core.upload(sc)
     core.bvh_build()
@@ -157,38 +123,15 @@ def main():
     params.tileRank, params.tileCount, params.tileSize = rank, world, 64
     core.set_params(params)
     seeds = scenes.frame_seeds(args.spp, seed=1)
-    n_local = core.local_pixel_count
-    local_buf = torch.zeros(n_local * 4, dtype=torch.float32, device=device)
-
-    # per-rank pixel maps so that rank 0 can place every rank's tiles (setup, untimed)
-    pm = torch.from_numpy(core.local_pixel_map().astype(np.int64)).to(device)
-    if world > 1:
-        sizes = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([n_local], dtype=torch.int64, device=device))
-        max_local = int(max(s.item() for s in sizes))
-        pm_pad = torch.full((max_local,), 0xFFFFFFFF, dtype=torch.int64, device=device)
-        pm_pad[:n_local] = pm
-        maps = [torch.empty_like(pm_pad) for _ in range(world)] if rank == 0 else None
-        dist.gather(pm_pad, maps, dst=0)
-        send_buf = torch.zeros(max_local * 4, dtype=torch.float32, device=device)
-        recv = [torch.empty_like(send_buf) for _ in range(world)] if rank == 0 else None
-    else:
-        maps, max_local, send_buf, recv = [pm], n_local, local_buf, None
-    frame = torch.zeros(args.width * args.height, 4, dtype=torch.float32, device=device) if rank == 0 else None
+    gatherer = rtdist.TileGatherer(args.width, args.height, 64, device)
+    assert gatherer.n_local == core.local_pixel_count
+    # the library's slot->pixel mapping and the host-side statement of it must agree
+    assert np.array_equal(rtdist.tile_pixel_map(args.width, args.height, 64, rank, world).astype(np.uint32), core.local_pixel_map())
 
     def gather_frame():
         """Accumulated tiles -> rank 0, once per finished image (device to device)."""
-        core.readback_local_device(wire.IMAGE_CONVERGED, local_buf.data_ptr())
-        if world > 1:
-            send_buf[: n_local * 4] = local_buf
-            dist.gather(send_buf, recv, dst=0)
-            parts = recv
-        else:
-            parts = [local_buf]
-        if rank == 0:
-            for m, part in zip(maps, parts):
-                valid = m != 0xFFFFFFFF
-                frame[m[valid]] = part.view(-1, 4)[: len(m)][valid]
+        core.readback_local_device(wire.IMAGE_CONVERGED, gatherer.local_buffer().data_ptr())
+        return gatherer.gather()
 
     def step():
         core.set_dirty()

@@ -25,8 +25,9 @@
 
 #define TRV_THREADS 256
 #define TRV_PEND_CAP 8          // queued triangle tests per lane
-#define TRV_NODE_BURST 24       // node steps between two triangle batches
-#define TRV_REFILL_MIN 20       // refill when at least this many lanes are idle
+#define TRV_NODE_BURST 48       // node steps between two triangle batches
+#define TRV_REFILL_MIN 24       // refill when at least this many lanes are idle
+#define TRV_EARLY_OUT 40        // leave a burst when this many lanes have nothing to walk
 #define TRV_DONE 0xFFFFFFFFu
 #define TRV_LDS_WORDS ((RT_STACK_DEPTH + TRV_PEND_CAP) * TRV_THREADS)
 
@@ -199,7 +200,7 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
             // a node step can queue two triangles: stop while there is still room for two
             if (__ballot(npend > TRV_PEND_CAP - 2) != 0ull) break;
             // many lanes finished: leave early so that they can be refilled
-            if (!exhausted && (uint32_t)__popcll(__ballot(!hasRay || node == TRV_DONE)) >= 32u) break;
+            if (!exhausted && (uint32_t)__popcll(__ballot(!hasRay || node == TRV_DONE)) >= (uint32_t)TRV_EARLY_OUT) break;
         }
 
         // ---- triangle phase: every lane tests its queued triangles in the order it met them

@@ -1,0 +1,282 @@
+"""Host-side mirror of the reference's C# driver classes, re-pointed at the C ABI.
+
+The reference host is C# (Unity MonoBehaviours) and no C# toolchain exists in
+this build environment, so the same surface is provided here in Python with the
+reference's class, field and method names; `csharp/RtCoreNative.cs` shows the
+P/Invoke form of the identical calls.  Mirrored:
+
+  RayTracing              Assets/Scripts/RayTracing/RayTracing.cs      Start, Update, CustomRender, SetDirty, OnDisable
+  BVH                     Assets/Scripts/BVH/BVH.cs:108-352            Init, InitMesh, InitMaterialData, UpdateMaterialData
+  LightImportanceSampling Assets/Scripts/RayTracing/LightImportanceSampling.cs:57-107   Init
+  DepthOfField            Assets/Scripts/PostProcess/DepthOfField.cs:22-44  UpdateParameter
+
+Unity objects (Transform, MeshRenderer, Material, Camera) are replaced by small
+data classes holding just the fields those methods read.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import scenes, wire
+from .native import RtCore
+
+
+# ------------------------------------------------------------------ stand-ins for Unity objects
+@dataclass
+class Transform:
+    position: tuple = (0.0, 0.0, 0.0)
+    rotation: tuple = scenes.IDENTITY_Q
+    localScale: tuple = (1.0, 1.0, 1.0)
+
+    @property
+    def forward(self):
+        return scenes.quat_rotate(self.rotation, np.array([0.0, 0.0, 1.0]))
+
+    @property
+    def up(self):
+        return scenes.quat_rotate(self.rotation, np.array([0.0, 1.0, 0.0]))
+
+
+@dataclass(eq=False)
+class Material:
+    """The shader properties MaterialData(Material) reads (BVH.cs:38-76)."""
+    color: tuple = (1.0, 1.0, 1.0, 1.0)          # sRGB, as in the .mat file
+    _Metallic: float = 0.0
+    _Glossiness: float = 0.5
+    _Mode: int = 0
+    _MaterialType: Optional[float] = None
+    _IOR: Optional[float] = None
+    _ClearCoatColor: Optional[tuple] = None
+    _EMISSION: bool = False
+    _EmissionColor: tuple = (0.0, 0.0, 0.0)
+
+    def MaterialData(self):
+        return scenes.material_data(self.color, self._Metallic, self._Glossiness, self._Mode,
+                                    self._EmissionColor if self._EMISSION else None,
+                                    0 if self._MaterialType is None else int(self._MaterialType),
+                                    1.0 if self._IOR is None else self._IOR,
+                                    (0, 0, 0) if self._ClearCoatColor is None else self._ClearCoatColor[:3])
+
+
+@dataclass
+class MeshRenderer:
+    sharedMesh: scenes.Mesh
+    sharedMaterial: Material
+    transform: Transform = field(default_factory=Transform)
+    enabled: bool = True
+    activeInHierarchy: bool = True
+    shadowCastingOn: bool = True
+    receiveShadows: bool = True
+
+
+@dataclass
+class LightObject:
+    """A child of sphereLightParent / areaLightParent / discLightParent."""
+    transform: Transform
+    colliderRadius: float = 0.5                  # SphereCollider.radius
+    colliderSize: tuple = (1.0, 1.0, 0.0)        # BoxCollider.size
+    active: bool = True
+
+
+@dataclass
+class Camera:
+    transform: Transform = field(default_factory=Transform)
+    fieldOfView: float = 60.0
+    nearClipPlane: float = 0.3
+    farClipPlane: float = 1000.0
+
+    def cameraToWorldMatrix(self):
+        return scenes.camera_to_world(self.transform.position, self.transform.rotation)
+
+    def inverseProjectionMatrix(self, aspect):
+        return scenes.inverse_projection(self.fieldOfView, aspect, self.nearClipPlane, self.farClipPlane)
+
+
+# ------------------------------------------------------------------ BVH.cs
+class BVH:
+    def __init__(self, meshParent: List[MeshRenderer]):
+        self.meshParent = meshParent
+        self.core: Optional[RtCore] = None
+        self.materials: List[Material] = []
+        self.mesh = None
+        self.onDirty = None                      # RayTracing.SetDirty (static in the reference)
+
+    def InitMesh(self):
+        """BVH.cs:201-318: merge every enabled, active renderer into one world-space
+        vertex/index buffer with per-triangle material index and shadow flags."""
+        mrs = [mr for mr in self.meshParent if mr.enabled and mr.activeInHierarchy]
+        b = scenes.SceneBuilder()
+        for mr in mrs:
+            b.add(mr.sharedMesh, mr.sharedMaterial, mr.transform.position, mr.transform.rotation, mr.transform.localScale,
+                  cast_shadow=mr.shadowCastingOn, receive_shadow=mr.receiveShadows)
+        materials = list(b.mats)
+        self.mesh = (np.concatenate(b.v), np.concatenate(b.i), np.concatenate(b.mi), np.concatenate(b.sh))
+        return self.mesh, materials
+
+    def InitMaterialData(self, materials):
+        self.materials = materials
+        datas = np.array([m.MaterialData() for m in materials], wire.MATERIAL)
+        self.core.materials_upload(datas)
+
+    def Init(self, core: RtCore):
+        """BVH.cs:108-199: upload mesh + materials, build, bind (binding is implicit here)."""
+        self.core = core
+        (v, i, mi, sh), materials = self.InitMesh()
+        core.scene_upload(v, i, mi, sh)
+        self.InitMaterialData(materials)
+        core.bvh_build()
+
+    def UpdateMaterialData(self):
+        """BVH.cs:334-352: re-read every material, re-upload, mark dirty."""
+        materials = []
+        for mr in self.meshParent:
+            if mr.enabled and mr.activeInHierarchy and not any(m is mr.sharedMaterial for m in materials):
+                materials.append(mr.sharedMaterial)
+        datas = np.array([m.MaterialData() for m in materials], wire.MATERIAL)
+        self.core.materials_upload(datas)
+        if self.onDirty:
+            self.onDirty()                       # RayTracing.SetDirty() (BVH.cs:351)
+
+
+# ------------------------------------------------------------------ LightImportanceSampling.cs
+class LightImportanceSampling:
+    def __init__(self, sphereLightParent=None, areaLightParent=None, discLightParent=None):
+        self.sphereLightParent = sphereLightParent or []
+        self.areaLightParent = areaLightParent or []
+        self.discLightParent = discLightParent or []
+
+    def Init(self, core: RtCore):
+        sph = [scenes.sphere_light(l.transform.position, l.colliderRadius, l.transform.localScale[0])
+               for l in self.sphereLightParent if l.active]
+        area = [scenes.area_light(l.transform.position, l.transform.rotation, l.colliderSize[:2], l.transform.localScale)
+                for l in self.areaLightParent if l.active]
+        disc = []
+        for l in self.discLightParent:
+            if l.active:
+                d = np.zeros((), wire.DISC_LIGHT)
+                d["position"] = np.asarray(l.transform.position, np.float32)
+                d["normal"] = (-l.transform.forward).astype(np.float32)
+                d["radius"] = np.float32(l.colliderRadius) * np.float32(l.transform.localScale[0])
+                disc.append(d)
+        core.lights_upload(np.array(sph, wire.SPHERE_LIGHT), np.array(area, wire.AREA_LIGHT), np.array(disc, wire.DISC_LIGHT))
+
+
+# ------------------------------------------------------------------ DepthOfField.cs
+@dataclass
+class DepthOfField:
+    enabled: bool = False
+    focalLength: float = 1.0
+    lensRadius: float = 0.0
+
+
+# ------------------------------------------------------------------ RayTracing.cs
+class RayTracing:
+    SamplingType = {"Uniform": 0, "Cosine": 1, "LightImportance": 2, "BSDFImportance": 3, "MultipleImportance": 4}
+
+    def __init__(self, cam: Camera, bvh: BVH, lightImportanceSampling: LightImportanceSampling, width, height,
+                 device_id=0, seed_source=None):
+        self.cam, self.bvh, self.lightImportanceSampling = cam, bvh, lightImportanceSampling
+        self.width, self.height = width, height
+        self.device_id = device_id
+        # public fields of the MonoBehaviour (RayTracing.cs:20-65)
+        self.skybox = None                       # skyboxMat _Tex: f32[6,S,S,4] or None
+        self.skyboxRotation = 0.0
+        self.skyboxExposure = 1.0
+        self.mainLightForward = (0.0, -1.0, 0.0)
+        self.mainLightColor = (1.0, 1.0, 1.0)
+        self.skyboxIntensityMulitiply = 2.0
+        self.shadowColor = (0.0, 0.0, 0.0)
+        self.lightRadius = 0.1
+        self.shadowIntensity = 1.0
+        self.aliasing = True
+        self.samplePrePixel = 0
+        self.useBVH = True
+        self.samplingType = "Uniform"
+        self.matteMaskGO = None
+        self.pause = False
+        self.depthOfField = DepthOfField()
+        self.isInitialized = False
+        self.isRenderMatteMask = False
+        self.core: Optional[RtCore] = None
+        self._seeds = seed_source or scenes.PCG32(1)      # stands in for UnityEngine.Random.value
+        self.params = None
+
+    # RayTracing.cs:68-97
+    def Start(self):
+        if not self.useBVH:
+            raise NotImplementedError("useBVH = false (brute-force primitives) is outside this library")
+        self.core = RtCore(self.device_id)
+        self.InitRT()
+        self.InitShader()
+        self.InitLight()
+        self.InitSampling()
+        self.bvh.onDirty = self.SetDirty
+        self.bvh.Init(self.core)
+        self.isInitialized = True
+
+    def InitRT(self):                            # :172-187
+        self.isRenderMatteMask = self.matteMaskGO is not None
+        self.samplePrePixel = 0
+
+    def InitShader(self):                        # :190-217
+        self.core.skybox_upload(self.skybox)
+
+    def InitLight(self):                         # :254-282
+        self.lightImportanceSampling.Init(self.core)
+
+    def InitSampling(self):                      # :285-311
+        if self.samplingType not in self.SamplingType:
+            raise ValueError(self.samplingType)
+
+    def UpdateParameters(self):                  # :219-239 (+ the Set* calls of InitShader/InitLight/InitSampling)
+        flags = self.SamplingType[self.samplingType]
+        if self.depthOfField.enabled:
+            flags |= wire.FLAG_DEPTH_OF_FIELD
+        if self.isRenderMatteMask:
+            flags |= wire.FLAG_MATTE_MASK
+        p = wire.RtParams()
+        p.width, p.height = self.width, self.height
+        p.camera2World[:] = self.cam.cameraToWorldMatrix().tolist()
+        p.cameraInverseProjection[:] = self.cam.inverseProjectionMatrix(self.width / self.height).tolist()
+        self._seeds.next_float()                 # pixelOffset.x  (uploaded, unused by the shader)
+        self._seeds.next_float()                 # pixelOffset.y
+        p.seed = float(self._seeds.next_float())
+        p.lightParameter[:] = [*[float(np.float32(c)) for c in self.mainLightForward], self.lightRadius]
+        p.lightColor[:] = [*self.mainLightColor, self.skyboxIntensityMulitiply]
+        p.shadowParameter[:] = [*self.shadowColor, self.shadowIntensity]
+        p.skyboxRotation, p.skyboxExposure = self.skyboxRotation, self.skyboxExposure
+        p.lensRadius, p.focalLength = self.depthOfField.lensRadius, self.depthOfField.focalLength
+        p.flags = flags
+        p.tileRank, p.tileCount, p.tileSize = 0, 1, 64
+        self.params = p
+        self.core.set_params(p)
+
+    # RayTracing.cs:118-164
+    def CustomRender(self):
+        if not self.isInitialized:
+            return None                          # the reference returns silently
+        self.UpdateParameters()
+        if not self.pause:
+            self.core.dispatch()
+        if self.isRenderMatteMask and not self.pause:
+            self.core.dispatch_shadowmap()
+        if not self.aliasing:
+            return self.core.readback(wire.IMAGE_RT)
+        self.core.accumulate(self.samplePrePixel, self.isRenderMatteMask)
+        self.samplePrePixel += 1
+        return None
+
+    def convergedRT(self):
+        return self.core.readback(wire.IMAGE_CONVERGED)
+
+    def SetDirty(self):                          # :314-317
+        self.samplePrePixel = 0
+        if self.core:
+            self.core.set_dirty()
+
+    def OnDisable(self):                         # :319-334
+        if self.core:
+            self.core.close()
+            self.core = None
+        self.isInitialized = False

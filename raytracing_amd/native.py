@@ -11,7 +11,8 @@ import numpy as np
 from . import wire
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtcore.so")
+# RTCORE_LIB lets a developer A/B another build of the same library; the default is the in-tree one.
+LIB_PATH = os.environ.get("RTCORE_LIB") or os.path.join(_HERE, "librtcore.so")
 
 # every symbol include/rtcore.h declares
 EXPORTS = [

@@ -479,12 +479,12 @@ def car_standin(width=1920, height=1080, detail=1.0, sampling=wire.SAMPLING_MIS,
     return scn
 
 
-def triangle_soup(n_triangles, seed=5, width=256, height=256):
-    """Random triangle soup: centres uniform in [-100,100]^3, edge vectors
-    uniform in [-0.5,0.5]^3, one diffuse material."""
+def triangle_soup(n_triangles, seed=5, width=256, height=256, extent=100.0, edge=0.5):
+    """Random triangle soup: centres uniform in [-extent,extent]^3, vertex offsets
+    uniform in [-edge,edge]^3, one diffuse material."""
     rs = np.random.Generator(np.random.PCG64(seed))
-    c = rs.uniform(-100, 100, (n_triangles, 1, 3))
-    e = rs.uniform(-0.5, 0.5, (n_triangles, 3, 3))
+    c = rs.uniform(-extent, extent, (n_triangles, 1, 3))
+    e = rs.uniform(-edge, edge, (n_triangles, 3, 3))
     p = (c + e).astype(F32).reshape(-1, 3)
     v = np.zeros(len(p), wire.MESH_VERTEX)
     v["position"] = p

@@ -1,0 +1,149 @@
+"""GPU tests at BASELINE's full sizes plus the host-mirror drive.  At 10 M
+triangles the whole build is still compared bit for bit with the CPU checker
+(which builds it in a few seconds) and, independently, through size-free
+properties: sortedness, permutation, stability, strictly increasing keys,
+boxes = unions of children."""
+import numpy as np
+import pytest
+
+from raytracing_amd import dist as rtdist
+from raytracing_amd import host, scenes, wire
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def test_local_pixel_map_matches_host_statement(core):
+    sc = scenes.cornell_box(200, 136, sphere_segments=8)
+    core.upload(sc)
+    core.bvh_build()
+    for rank, world, ts in ((0, 1, 64), (1, 3, 32), (2, 3, 32), (7, 8, 64)):
+        p = sc.params.copy()
+        p.tileRank, p.tileCount, p.tileSize = rank, world, ts
+        core.set_params(p)
+        np.testing.assert_array_equal(core.local_pixel_map(), rtdist.tile_pixel_map(200, 136, ts, rank, world).astype(np.uint32))
+
+
+def test_host_mirror_drives_the_library_like_the_reference_driver(oracle):
+    """RayTracing.Start + 3 x CustomRender through the mirrored classes == checker."""
+    sc = scenes.cornell_box(64, 48, sphere_segments=8)
+    grey = host.Material((0.6792453, 0.6792453, 0.6792453, 1), 0, 0.5)
+    red = host.Material((0.9056604, 0, 0, 1), 0, 0.5)
+    lamp = host.Material((1, 1, 1, 1), 0, 0.5, _EMISSION=True, _EmissionColor=(1, 1, 1))
+    glass = host.Material((0.6792453, 0.6792453, 0.6792453, 0.20784314), 0, 0.867, _Mode=3, _IOR=1.1, _MaterialType=0)
+    s = 0.7071068
+    q, sph = scenes.quad_mesh(), scenes.uv_sphere_mesh(16, 8)
+    T = host.Transform
+    mrs = [host.MeshRenderer(q, grey, T((0, 0, 0), (s, 0, 0, s), (20, 20, 1)), shadowCastingOn=False),
+           host.MeshRenderer(q, red, T((10, 7.5, 0), (0, s, 0, s), (20, 15, 1)), shadowCastingOn=False),
+           host.MeshRenderer(q, grey, T((0, 7.5, 10), scenes.IDENTITY_Q, (20, 15, 1)), shadowCastingOn=False),
+           host.MeshRenderer(q, lamp, T((0, 14.97, 0), (-s, 0, 0, s), (6, 6, 6))),
+           host.MeshRenderer(sph, glass, T((2.81, 1.95, -7.79), scenes.IDENTITY_Q, (1.8472177,) * 3))]
+    lights = host.LightImportanceSampling(areaLightParent=[host.LightObject(T((0, 14.97, 0), (-s, 0, 0, s), (6, 6, 6)),
+                                                                            colliderSize=(1, 1.0000002, 0))])
+    cam = host.Camera(T((0, 5.8, -21.2)), fieldOfView=50.0)
+    rt = host.RayTracing(cam, host.BVH(mrs), lights, 64, 48, seed_source=scenes.PCG32(3))
+    rt.samplingType = "MultipleImportance"
+    rt.skybox = sc.skybox
+    rt.skyboxIntensityMulitiply = 1.0
+    assert rt.CustomRender() is None                    # not initialised: silently nothing
+    rt.Start()
+    for _ in range(3):
+        rt.CustomRender()
+    assert rt.samplePrePixel == 3
+    got = rt.convergedRT()
+
+    # the same scene and seeds through the checker
+    (v, i, mi, sh), mats = host.BVH(mrs).InitMesh()
+    ref = scenes.Scene("mirror", v, i, mi, sh, np.array([m.MaterialData() for m in mats], wire.MATERIAL),
+                       area_lights=np.array([scenes.area_light((0, 14.97, 0), (-s, 0, 0, s), (1, 1.0000002), (6, 6, 6))], wire.AREA_LIGHT),
+                       skybox=sc.skybox)
+    g = scenes.PCG32(3)
+    seeds = []
+    for _ in range(3):
+        g.next_float(), g.next_float()
+        seeds.append(g.next_float())
+    orc = oracle.Oracle(ref).build()
+    want = oracle.render_frames(orc, rt.params, seeds)
+    assert H.relative_l2(got, want).max() <= 1e-3
+    # material edit -> UpdateMaterialData -> dirty (BVH.cs:334-352, CustomMaterialInfo presets)
+    red.color = (0.1, 0.1, 0.9, 1)
+    rt.bvh.UpdateMaterialData()
+    assert rt.samplePrePixel == 0 and rt.core.sample_count == 0
+    rt.CustomRender()
+    after = rt.convergedRT()
+    assert np.abs(after[..., 2] - got[..., 2]).max() > 0.01          # the wall turned blue
+    rt.OnDisable()
+
+
+@pytest.fixture(scope="module")
+def soup10m():
+    return scenes.triangle_soup(10_000_000, seed=5)
+
+
+def test_build_10m_triangles_bit_exact_and_properties(core, oracle, soup10m):
+    sc = soup10m
+    n = sc.n_triangles
+    core.upload(sc)
+    core.bvh_build()
+    print(f"\n10M build: {core.stats()['buildMs']:.2f} ms device time")
+    got = core.readback_bvh()
+    # ---- size-independent properties (no checker involved)
+    raw, idx, codes = got["morton_sorted_raw"], got["sorted_index"], got["morton"]
+    assert (np.diff(raw.astype(np.int64)) >= 0).all()                               # sorted
+    assert np.array_equal(np.sort(idx), np.arange(n, dtype=np.uint32))              # a permutation
+    assert np.array_equal(raw, got["morton_unsorted"][idx])                         # keys travelled with their values
+    same = np.diff(raw.astype(np.int64)) == 0
+    assert (np.diff(idx.astype(np.int64))[same] > 0).all()                          # stable: ties keep triangle order
+    assert codes[0] == 0 and np.array_equal(np.diff(codes.astype(np.int64)), np.maximum(np.diff(raw.astype(np.int64)), 1))
+    inner = got["internal"]
+    assert inner["parent"][0] == 0xFFFFFFFF and np.array_equal(inner["index"], np.arange(n - 1, dtype=np.uint32))
+    li = inner["leftNodeType"] == wire.INTERNAL
+    ri = inner["rightNodeType"] == wire.INTERNAL
+    assert np.array_equal(inner["parent"][inner["leftNode"][li]], np.nonzero(li)[0].astype(np.uint32))
+    assert np.array_equal(inner["parent"][inner["rightNode"][ri]], np.nonzero(ri)[0].astype(np.uint32))
+    assert np.array_equal(got["leaves"]["parent"][inner["leftNode"][~li]], np.nonzero(~li)[0].astype(np.uint32))
+    assert np.array_equal(inner["rightNode"], inner["leftNode"] + 1)
+    assert li.sum() + ri.sum() == n - 2 and (~li).sum() + (~ri).sum() == n          # every node / leaf has one parent
+    lb_min = np.where(li[:, None], got["bvh_data"]["min"][np.where(li, inner["leftNode"], 0)],
+                      got["tri_aabb"]["min"][idx[np.where(li, 0, inner["leftNode"])]])
+    rb_min = np.where(ri[:, None], got["bvh_data"]["min"][np.where(ri, inner["rightNode"], 0)],
+                      got["tri_aabb"]["min"][idx[np.where(ri, 0, inner["rightNode"])]])
+    assert np.array_equal(got["bvh_data"]["min"], np.minimum(lb_min, rb_min))       # every box = union of its children
+    np.testing.assert_array_equal(got["bvh_data"]["min"][0], got["tri_aabb"]["min"].min(0))
+    np.testing.assert_array_equal(got["bvh_data"]["max"][0], got["tri_aabb"]["max"].max(0))
+    # ---- and bit for bit against the checker (the reference itself caps at 524 288 triangles)
+    want = oracle.Oracle(sc).build().readback_bvh()
+    for key in ("morton_unsorted", "morton_sorted_raw", "morton", "sorted_index", "tri_aabb", "internal", "leaves", "bvh_data"):
+        assert got[key].tobytes() == want[key].tobytes(), key
+
+
+def test_traversal_stress_10m(core, oracle, soup10m):
+    sc = soup10m
+    core.upload(sc)
+    core.bvh_build()
+    n = 1 << 19
+    o, d = scenes.stress_rays(n, seed=7)
+    core.reset_stats()
+    got = core.trace_rays(o, d)
+    ms = core.stats()["renderMs"]
+    again = core.trace_rays(o, d)
+    for k in ("t", "triangle", "u", "v"):
+        assert got[k].tobytes() == again[k].tobytes()                              # idempotent
+    hit = got["triangle"] != 0xFFFFFFFF
+    assert hit.mean() > 0.5 and np.isinf(got["t"][~hit]).all()
+    assert (got["t"][hit] > 0).all() and (got["u"][hit] >= 0).all() and (got["v"][hit] >= 0).all()
+    assert (got["u"][hit] + got["v"][hit] <= 1).all()
+    # the reported point lies on the reported triangle (float64 re-evaluation)
+    sel = np.nonzero(hit)[0][:20000]
+    tri = sc.vertices["position"].astype(np.float64).reshape(-1, 3, 3)[got["triangle"][sel]]
+    u, v = got["u"][sel, None].astype(np.float64), got["v"][sel, None].astype(np.float64)
+    on_tri = tri[:, 0] * (1 - u - v) + tri[:, 1] * u + tri[:, 2] * v
+    on_ray = o[sel].astype(np.float64) + d[sel].astype(np.float64) * got["t"][sel, None].astype(np.float64)
+    assert np.abs(on_tri - on_ray).max() < 2e-2        # float32 Moller-Trumbore at grazing incidence
+    # a sample against the checker, bit for bit
+    pick = np.arange(0, n, n // 4096)[:4096]
+    want = oracle.Oracle(sc).build().trace(o[pick], d[pick])
+    H.assert_bits_equal(got["triangle"][pick], want["triangle"], "stress first-hit ids")
+    H.assert_bits_equal(got["t"][pick], want["t"], "stress distances")
+    print(f"\n10M soup: {n} incoherent rays in {ms:.2f} ms = {n / ms / 1e3:.1f} Mrays/s")

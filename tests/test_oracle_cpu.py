@@ -1,0 +1,354 @@
+"""CPU checks of the checker itself (oracle/): hand-derived known answers,
+brute-force properties and the committed golden fixtures.  The reference has no
+tests or vectors for this path (parity unpinned), so these are what pins it."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from raytracing_amd import scenes, wire
+from tests import helpers as H
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ------------------------------------------------------------------ Morton codes (MeshData.compute:41-60)
+def _interleave3(x, y, z):
+    code = 0
+    for b in range(10):
+        code |= ((x >> b) & 1) << (3 * b + 2) | ((y >> b) & 1) << (3 * b + 1) | ((z >> b) & 1) << (3 * b)
+    return code
+
+
+def test_morton_known_answers(oracle):
+    assert oracle.morton_code(0.0, 0.0, 0.0) == 0
+    assert oracle.morton_code(1.0, 1.0, 1.0) == 0x3FFFFFFF            # clamps to 1023
+    assert oracle.morton_code(2.0, -3.0, float("nan")) == _interleave3(1023, 0, 0)
+    assert oracle.morton_code(1 / 1024, 0, 0) == 4 and oracle.morton_code(0, 1 / 1024, 0) == 2
+    assert oracle.morton_code(0, 0, 1 / 1024) == 1
+    assert oracle.morton_code(0.5, 0.5, 0.5) == _interleave3(512, 512, 512)
+    rs = np.random.Generator(np.random.PCG64(1))
+    for x, y, z in rs.uniform(0, 1, (200, 3)).astype(np.float32):
+        cell = [min(int(np.float32(c) * np.float32(1024.0)), 1023) for c in (x, y, z)]
+        assert oracle.morton_code(float(x), float(y), float(z)) == _interleave3(*cell)
+
+
+def test_morton_uses_fixed_125_box(oracle):
+    """A triangle at the origin lands in the centre cell of the +-125 box whatever the mesh bounds are."""
+    sc = scenes.triangle_soup(1, seed=1)
+    v = sc.vertices.copy()
+    v["position"] = np.array([[0, 0, 0], [0.01, 0, 0], [0, 0.01, 0]], np.float32)
+    sc.vertices = v
+    rb = oracle.Oracle(sc).build().readback_bvh()
+    assert rb["morton_unsorted"][0] == _interleave3(512, 512, 512)
+    np.testing.assert_array_equal(rb["tri_aabb"]["min"][0], np.float32([0, 0, 0]) - np.float32(0.001))
+    np.testing.assert_array_equal(rb["tri_aabb"]["max"][0], np.float32([0.01, 0.01, 0]) + np.float32(0.001))
+
+
+# ------------------------------------------------------------------ sort (stable LSD) and its validators
+def test_radix_sort_is_stable_and_conserves_histograms(oracle):
+    rs = np.random.Generator(np.random.PCG64(2))
+    keys = rs.integers(0, 50, 20000, dtype=np.uint32) * np.uint32(0x01010101)     # duplicate-heavy, all four digits used
+    keys[::7] = 0xFFFFFFFF
+    vals = np.arange(len(keys), dtype=np.uint32)
+    k, v = oracle.radix_sort(keys, vals)
+    order = np.argsort(keys, kind="stable")
+    np.testing.assert_array_equal(k, keys[order])
+    np.testing.assert_array_equal(v, vals[order])                    # ties keep their original order
+    assert (np.diff(k.astype(np.int64)) >= 0).all()                  # ComputeBufferSorter.cs:155-182
+    for shift in (0, 8, 16, 24):                                     # per-digit histogram conservation (:198-277)
+        np.testing.assert_array_equal(np.bincount((keys >> shift) & 255, minlength=256),
+                                      np.bincount((k >> shift) & 255, minlength=256))
+
+
+# ------------------------------------------------------------------ DistributeMortonCode
+def test_distribute_morton_known_answer(oracle):
+    np.testing.assert_array_equal(oracle.distribute_morton([5, 5, 5, 7, 7, 10]), [0, 1, 2, 4, 5, 8])
+    np.testing.assert_array_equal(oracle.distribute_morton([9]), [0])
+    rs = np.random.Generator(np.random.PCG64(3))
+    k = np.sort(rs.integers(0, 1 << 30, 5000, dtype=np.uint32))
+    k[100:400] = k[100]
+    out = oracle.distribute_morton(k)
+    assert out[0] == 0 and (np.diff(out.astype(np.int64)) >= 1).all()
+    np.testing.assert_array_equal(np.diff(out.astype(np.int64)), np.maximum(np.diff(k.astype(np.int64)), 1))
+
+
+# ------------------------------------------------------------------ Karras tree
+def _clz32(v):
+    return 32 if v == 0 else 32 - int(v).bit_length()
+
+
+def _check_tree(codes, internal, leaves):
+    """Structural invariants of the binary radix tree over strictly increasing keys."""
+    n = len(codes)
+    lo, hi = {}, {}
+
+    def span(idx, kind):
+        if kind == wire.LEAF:
+            return idx, idx
+        return lo[idx], hi[idx]
+
+    # ranges bottom-up by recursion from the root
+    def fill(i):
+        nd = internal[i]
+        for side in ("left", "right"):
+            c, t = int(nd[side + "Node"]), int(nd[side + "NodeType"])
+            if t == wire.INTERNAL:
+                assert int(internal[c]["parent"]) == i
+                fill(c)
+            else:
+                assert int(leaves[c]["parent"]) == i and int(leaves[c]["index"]) == c
+        l0, l1 = span(int(nd["leftNode"]), int(nd["leftNodeType"]))
+        r0, r1 = span(int(nd["rightNode"]), int(nd["rightNodeType"]))
+        assert l1 + 1 == r0, "children must tile the parent's range"
+        lo[i], hi[i] = l0, r1
+        assert int(nd["index"]) == i
+        # Karras: an internal node sits at one end of its range; children are split and split+1
+        assert i in (l0, r1) and int(nd["leftNode"]) == l1 and int(nd["rightNode"]) == r0
+        # split = highest index sharing more than the range's common prefix with the first key
+        cp = _clz32(int(codes[l0]) ^ int(codes[r1]))
+        assert all(_clz32(int(codes[l0]) ^ int(codes[k])) > cp for k in range(l0, l1 + 1))
+        assert _clz32(int(codes[l0]) ^ int(codes[r0])) == cp
+        # maximality: neighbours outside the range share a shorter prefix
+        if l0 > 0:
+            assert _clz32(int(codes[l0 - 1]) ^ int(codes[l0])) < cp
+        if r1 < n - 1:
+            assert _clz32(int(codes[r1]) ^ int(codes[r1 + 1])) < cp
+
+    fill(0)
+    assert (lo[0], hi[0]) == (0, n - 1) and int(internal[0]["parent"]) == 0xFFFFFFFF
+    assert len(lo) == n - 1, "every internal node is reachable exactly once"
+
+
+def test_tree_hand_derived(oracle):
+    inodes, leaves = oracle.tree_from_codes([3, 9])
+    assert tuple(inodes[0]) == (0, wire.LEAF, 1, wire.LEAF, 0xFFFFFFFF, 0)
+    assert [tuple(l) for l in leaves] == [(0, 0), (0, 1)]
+    # keys 0b000, 0b001, 0b100: root splits after index 1; node 1 = {0,1}; leaf 2 hangs off the root
+    inodes, leaves = oracle.tree_from_codes([0, 1, 4])
+    assert tuple(inodes[0]) == (1, wire.INTERNAL, 2, wire.LEAF, 0xFFFFFFFF, 0)
+    assert tuple(inodes[1]) == (0, wire.LEAF, 1, wire.LEAF, 0, 1)
+    assert [tuple(l) for l in leaves] == [(1, 0), (1, 1), (0, 2)]
+    # eight consecutive keys: the perfect tree
+    inodes, leaves = oracle.tree_from_codes(list(range(8)))
+    assert tuple(inodes[0])[:4] == (3, wire.INTERNAL, 4, wire.INTERNAL)
+    assert tuple(inodes[3])[:4] == (1, wire.INTERNAL, 2, wire.INTERNAL) and tuple(inodes[4])[:4] == (5, wire.INTERNAL, 6, wire.INTERNAL)
+    for i, (a, b) in {1: (0, 1), 2: (2, 3), 5: (4, 5), 6: (6, 7)}.items():
+        assert tuple(inodes[i])[:4] == (a, wire.LEAF, b, wire.LEAF)
+    # N = 1: nothing is linked (TreeConstructor runs for no thread)
+    inodes, leaves = oracle.tree_from_codes([7])
+    assert len(inodes) == 0 and tuple(leaves[0]) == (0xFFFFFFFF, 0xFFFFFFFF)
+
+
+@pytest.mark.parametrize("n,seed", [(2, 1), (3, 2), (17, 3), (257, 4), (1500, 5)])
+def test_tree_invariants_random(oracle, n, seed):
+    rs = np.random.Generator(np.random.PCG64(seed))
+    raw = np.sort(rs.integers(0, 1 << 30, n, dtype=np.uint32))
+    raw[n // 3: n // 2] = raw[n // 3]
+    codes = oracle.distribute_morton(raw)
+    inodes, leaves = oracle.tree_from_codes(codes)
+    _check_tree(codes, inodes, leaves)
+
+
+def test_bvh_boxes_are_subtree_unions(oracle):
+    sc = H.duplicate_heavy_scene(1200, seed=4)
+    rb = oracle.Oracle(sc).build().readback_bvh()
+    _check_tree(rb["morton"], rb["internal"], rb["leaves"])
+    tmin, tmax = rb["tri_aabb"]["min"][rb["sorted_index"]], rb["tri_aabb"]["max"][rb["sorted_index"]]
+    first = {}
+
+    def rng_of(i):
+        nd = rb["internal"][i]
+        spans = []
+        for side in ("left", "right"):
+            c, t = int(nd[side + "Node"]), int(nd[side + "NodeType"])
+            spans.append((c, c) if t == wire.LEAF else rng_of(c))
+        first[i] = (spans[0][0], spans[1][1])
+        return first[i]
+
+    rng_of(0)
+    for i, (a, b) in first.items():
+        np.testing.assert_array_equal(rb["bvh_data"]["min"][i], tmin[a:b + 1].min(0))
+        np.testing.assert_array_equal(rb["bvh_data"]["max"][i], tmax[a:b + 1].max(0))
+    assert sorted(rb["sorted_index"]) == list(range(sc.n_triangles))
+
+
+# ------------------------------------------------------------------ traversal vs brute force
+def test_bvh_traversal_equals_brute_force(oracle):
+    sc = scenes.triangle_soup(3000, seed=11, extent=10.0, edge=1.0)
+    orc = oracle.Oracle(sc).build()
+    o, d = H.random_rays(4000, 5, -11, 11)
+    a, b = orc.trace(o, d), orc.trace(o, d, brute=True)
+    H.assert_bits_equal(a["t"], b["t"], "BVH vs brute-force distance")
+    assert (a["triangle"] == b["triangle"]).mean() > 0.999          # differs only on exact-distance ties
+    assert (a["triangle"] != 0xFFFFFFFF).sum() > 50
+    c = a["counters"]
+    assert c["rays"] == 4000 and c["hits"] == (a["triangle"] != 0xFFFFFFFF).sum()
+    assert c["internalVisits"] >= c["rays"] and c["triTests"] <= c["leafVisits"]
+
+
+def test_backface_culling_and_single_triangle(oracle):
+    sc = scenes.triangle_soup(2, seed=1)
+    v = sc.vertices.copy()
+    v["position"] = np.array([[0, 0, 0], [1, 1, 0], [1, 0, 0], [5, 5, 5], [6, 6, 5], [6, 5, 5]], np.float32)   # Unity quad winding
+    sc.vertices = v
+    orc = oracle.Oracle(sc).build()
+    o = np.array([[0.7, 0.3, -1], [0.7, 0.3, 1]], np.float32)
+    d = np.array([[0, 0, 1], [0, 0, -1]], np.float32)
+    r = orc.trace(o, d)
+    assert r["triangle"][0] == 0 and r["t"][0] == 1.0                # front face (det > 0)
+    assert r["triangle"][1] == 0xFFFFFFFF                            # back face culled (det < 1e-8)
+    one = scenes.triangle_soup(1, seed=1)
+    one.vertices = v[:3]
+    assert oracle.Oracle(one).build().trace(o, d)["triangle"].tolist() == [0xFFFFFFFF] * 2   # N = 1: zero root box, no hit
+
+
+# ------------------------------------------------------------------ numeric rules
+def _ulp_err(got, want64):
+    want32 = want64.astype(np.float32)
+    ulp = np.spacing(np.abs(want32)).astype(np.float64)
+    return np.abs(got.astype(np.float64) - want64) / np.maximum(ulp, 1e-45)
+
+
+def test_rt_math_accuracy(oracle):
+    rs = np.random.Generator(np.random.PCG64(7))
+    x = np.concatenate([rs.uniform(-3e5, 3e5, 100000), rs.uniform(-8, 8, 100000)]).astype(np.float32)
+    assert _ulp_err(oracle.math(0, x), np.sin(x.astype(np.float64))).max() <= 0.51
+    assert _ulp_err(oracle.math(1, x), np.cos(x.astype(np.float64))).max() <= 0.51
+    u = rs.uniform(-1, 1, 100000).astype(np.float32)
+    assert _ulp_err(oracle.math(2, u), np.arccos(u.astype(np.float64))).max() <= 0.51
+    a, b = rs.uniform(1e-3, 4, 100000).astype(np.float32), rs.uniform(-4, 8, 100000).astype(np.float32)
+    assert _ulp_err(oracle.math(3, a, b), np.power(a.astype(np.float64), b.astype(np.float64))).max() <= 0.52
+    sp = np.array([0.0, 2.0, -1.0, np.inf, np.nan], np.float32)
+    r = oracle.math(3, sp, np.array([2.0, 0.5, 2.0, 2.0, 1.0], np.float32))
+    assert r[0] == 0 and abs(r[1] - np.sqrt(2)) < 1e-6 and np.isnan(r[2]) and np.isinf(r[3]) and np.isnan(r[4])
+    f = oracle.math(6, np.array([-1.5, 0.0, 3.99, 4294967040.0, 4294967296.0, np.nan, 1e20], np.float32)).view(np.uint32)
+    assert f.tolist() == [0, 0, 3, 4294967040, 0xFFFFFFFF, 0, 0xFFFFFFFF]         # D3D ftou
+
+
+def test_golden_rand_and_math(oracle):
+    rand = json.load(open(os.path.join(GOLD, "rand_kat.json")))
+    for key, ref in rand.items():
+        px, py = map(int, key.split(","))
+        vals, states = oracle.rand_sequence(px, py, 0.25, 16)
+        assert vals.view(np.uint32).tolist() == ref["bits"] and states.tolist() == ref["state"]
+        assert ((vals >= 0) & (vals < 1)).all()
+    # pixel (0,0): dot(pixel, .) = 0, so sin(.) = 0 and the xorshift state never leaves 0 -- every Rand() is 0
+    assert set(rand["0,0"]["state"]) == {0} and set(rand["0,0"]["bits"]) == {0}
+    v, st = oracle.rand_sequence(0, 5, 0.25, 4)        # on an axis the state starts at 0 but moves on
+    assert st[0] != 0 and len(set(st.tolist())) == 4
+    m = json.load(open(os.path.join(GOLD, "math_kat.json")))
+    x = np.array(m["x"], np.uint32).view(np.float32)
+    u = np.array(m["u"], np.uint32).view(np.float32)
+    y = np.array(m["y"], np.uint32).view(np.float32)
+    for name, which, a, b in (("sin", 0, x, None), ("cos", 1, x, None), ("acos", 2, u, None), ("pow", 3, np.abs(u), y),
+                              ("srgb2lin", 4, np.abs(u), None), ("lin2srgb", 5, np.abs(u), None)):
+        assert oracle.math(which, a, b).view(np.uint32).tolist() == m[name], name
+
+
+def test_rand_is_uniform_enough(oracle):
+    vals = np.concatenate([oracle.rand_sequence(px, py, 0.37, 64)[0] for px in range(3, 40) for py in range(5, 30)])
+    assert abs(vals.mean() - 0.5) < 0.02 and abs(np.mean(vals < 0.25) - 0.25) < 0.02
+
+
+# ------------------------------------------------------------------ shading functions against float64 formulas
+def test_brdf_table_matches_float64_formulas(oracle):
+    rs = np.random.Generator(np.random.PCG64(9))
+    n = 2000
+    nrm = np.tile(np.array([0.0, 1.0, 0.0]), (n, 1))
+
+    def hemi():
+        v = rs.normal(size=(n, 3))
+        v[:, 1] = np.abs(v[:, 1]) + 0.05
+        return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+    V, L = hemi(), hemi()
+    dirs = np.concatenate([V, L, nrm], 1).astype(np.float32)
+    p = scenes.make_params(8, 8, (0, 0, -1), light_color=(1.0, 0.9, 0.8), sky_intensity=2.0)
+    for metallic, smooth in ((0.01, 0.5), (1.0, 0.9), (0.5, 0.01)):
+        m = scenes.material_data((0.8, 0.4, 0.2, 1), metallic, smooth)
+        got = oracle.brdf_table(p, np.array([m], wire.MATERIAL), dirs)
+        V64, L64 = dirs[:, 0:3].astype(np.float64), dirs[:, 3:6].astype(np.float64)
+        Hh = V64 + L64
+        Hh /= np.linalg.norm(Hh, axis=1, keepdims=True)
+        alb = m["albedo"].astype(np.float64)
+        met, pr = float(m["metallic"]), 1 - float(m["smoothness"])
+        rough = max(pr * pr, 0.002)
+        nv, nl = V64[:, 1].clip(0, 1), L64[:, 1].clip(0, 1)
+        nh, lh, hv = Hh[:, 1].clip(0, 1), (L64 * Hh).sum(1).clip(0, 1), (Hh * V64).sum(1).clip(0, 1)
+        PI = 3.14159265
+        spec = 0.04 + met * (alb - 0.04)
+        diffuse = alb * (0.96 - met * 0.96)
+        fd90 = 0.5 + 2 * lh * lh * pr
+        dterm = (1 + (fd90 - 1) * (1 - nl) ** 5) * (1 + (fd90 - 1) * (1 - nv) ** 5) * nl
+        dbrdf = diffuse[None] * dterm[:, None] / PI
+        a2 = rough * rough
+        dd = (nh * a2 - nh) * nh + 1
+        D = a2 / (PI * (dd * dd + 1e-7))
+        F = spec[None] + (1 - spec[None]) * ((1 - hv) ** 5)[:, None]
+        k = (rough + 1) ** 2 / 8
+        G = (nl / (nl * (1 - k) + k)) * (nv / (nv * (1 - k) + k))
+        sbrdf = (D * G)[:, None] * F / (4 * np.abs(V64[:, 1]) * nl + 0.001)[:, None]
+        lc = np.array([1.0, 0.9, 0.8]) * 2.0
+        kD = (1 - F) * (1 - met)
+        func = (dbrdf * kD * lc / 2 + sbrdf * lc) * nl[:, None]
+        dr = 0.5 * (1 - met)
+        pdf = nl / PI * dr + D * nh / (4 * hv) * (1 - dr)
+        np.testing.assert_allclose(got[:, :3], func, rtol=3e-3, atol=1e-6)
+        np.testing.assert_allclose(got[:, 3], pdf, rtol=3e-3, atol=1e-6)
+
+
+# ------------------------------------------------------------------ accumulation (AddShader)
+def test_accumulate_is_a_running_mean(oracle):
+    rs = np.random.Generator(np.random.PCG64(12))
+    frames = rs.uniform(0, 2, (5, 4, 4, 4)).astype(np.float32)
+    conv = np.full((4, 4, 4), 7.0, np.float32)        # stale content must be overwritten by frame 0 (a = 1)
+    for k, f in enumerate(frames):
+        oracle.accumulate(conv, f, None, k, False)
+    np.testing.assert_allclose(conv[..., :3], frames[..., :3].mean(0), rtol=1e-6)
+    a = 1.0
+    for k in range(5):
+        s = np.float32(1.0) / (np.float32(k) + np.float32(1.0))
+        a = s * s + np.float32(a) * (np.float32(1.0) - s)
+    assert conv[0, 0, 3] == np.float32(a)
+    sm = np.full((4, 4, 4), 0.5, np.float32)
+    conv2 = np.zeros((4, 4, 4), np.float32)
+    oracle.accumulate(conv2, frames[0], sm, 0, True)
+    np.testing.assert_array_equal(conv2[..., :3], frames[0][..., :3] * np.float32(0.5))
+
+
+# ------------------------------------------------------------------ golden image / BVH fixture
+def test_golden_cornell_fixture(oracle):
+    g = np.load(os.path.join(GOLD, "cornell_64x64x4.npz"))
+    sc = scenes.cornell_box(64, 64, sphere_segments=16)
+    orc = oracle.Oracle(sc).build()
+    rb = orc.readback_bvh()
+    for key in ("morton", "sorted_index", "internal", "bvh_data"):
+        H.assert_bits_equal(rb[key], g[key], f"golden {key}")
+    img = oracle.render_frames(orc, sc.params, g["seeds"])
+    H.assert_bits_equal(img, g["image"], "golden Cornell image")
+    o, d = H.camera_rays(sc.params, 64)
+    hit = orc.trace(o, d)
+    H.assert_bits_equal(hit["triangle"], g["first_hit_triangle"], "golden first-hit ids")
+    H.assert_bits_equal(hit["t"], g["first_hit_t"], "golden first-hit distance")
+
+
+def test_emissive_hit_is_readded_for_every_remaining_bounce(oracle):
+    """Shade.cginc:62-63 leaves ray and energy untouched on an emissive hit, so a
+    camera ray that sees the lamp directly accumulates 8 x emission."""
+    sc = scenes.cornell_box(64, 64, sphere_segments=8, with_sky=False)
+    p = sc.params.copy()
+    p.camera2World[:] = scenes.camera_to_world((0, 8, 0), scenes.quat_from_euler_deg(-90, 0, 0)).tolist()   # look straight up at the lamp
+    img = oracle.Oracle(sc).build().render(p)
+    centre = img[28:36, 28:36, :3]
+    np.testing.assert_array_equal(centre, np.float32(8.0))
+
+
+def test_matte_mask_and_shadowmap_alpha(oracle):
+    sc = scenes.car_standin(48, 32, detail=0.02)
+    orc = oracle.Oracle(sc).build()
+    sm = orc.shadowmap(sc.params)
+    assert set(np.unique(sm[..., 3])) <= {0.0, 1.0}
+    assert (sm[..., 3] == 1).any() and (sm[..., 3] == 0).any()       # car pixels 1, ground (type 4) and sky 0
+    assert sm[..., :3].min() >= 1 - sc.params.shadowParameter[3] - 1e-6
