@@ -55,6 +55,7 @@ struct RayHit {         // Header.cginc:40-58
 
 struct TraceCounters {
     uint64_t rays, internalVisits, leafVisits, triTests, hits;
+    uint32_t *nodeVisits = nullptr;   // optional per-node histogram of passed internal nodes (analysis only)
 };
 
 struct Scene {
@@ -436,6 +437,7 @@ void IntersectTriangle(const Scene &s, const Ray &ray, RayHit &hit, TraceCounter
         if (cnt) cnt->internalVisits++;
         const RtAABB &box = s.N >= 2 ? s.bvhData[index] : zeroBox;
         if (!RayBoxIntersection(box, ray)) continue;
+        if (cnt && cnt->nodeVisits) __atomic_fetch_add(&cnt->nodeVisits[index], 1u, __ATOMIC_RELAXED);
         const RtInternalNode &n = s.inodes[index];
         if (n.leftNodeType == RT_INTERNAL_NODE) {
             stack[currentStackIndex] = n.leftNode;
@@ -1156,6 +1158,10 @@ void orc_tree_from_codes(const uint32_t *codes, uint32_t n, RtInternalNode *inod
     memcpy(leaves, s.leaves.data(), (size_t)n * sizeof(RtLeafNode));
 }
 
+static uint32_t *g_nodeVisits = nullptr;
+// Analysis aid: while set, orc_trace adds 1 to visits[node] for every internal node whose box a ray passes.
+void orc_set_node_visit_histogram(uint32_t *visits) { g_nodeVisits = visits; }
+
 // First-hit queries.  counters (5 x u64: rays, internal, leaf, tri, hits) may be NULL.
 void orc_trace(void *h, const float *o, const float *d, uint32_t n, float *out_t, uint32_t *out_tri,
                float *out_u, float *out_v, uint64_t *counters)
@@ -1165,6 +1171,7 @@ void orc_trace(void *h, const float *o, const float *d, uint32_t n, float *out_t
 #pragma omp parallel
     {
         TraceCounters c = {0, 0, 0, 0, 0};
+        c.nodeVisits = g_nodeVisits;
         Thread th;
         th.sc = &s;
         th.P = nullptr;

@@ -311,18 +311,11 @@ int rt_render_frames(RtContext *ctx, const float *seeds, uint32_t n_frames)
     int rc = ready_to_render(ctx);
     if (rc) return rc;
     if (n_frames && !seeds) return rt_fail(ctx, RT_E_INVALID, "null seeds");
-    const bool matte = (ctx->params.flags & RT_FLAG_MATTE_MASK) != 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     RT_HIP(ctx, hipEventCreate(&e0));
     RT_HIP(ctx, hipEventCreate(&e1));
     RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
-    for (uint32_t k = 0; k < n_frames; ++k) {
-        ctx->params.seed = seeds[k];
-        if ((rc = rt_dispatch_impl(ctx))) return rc;
-        if (matte && (rc = rt_shadowmap_impl(ctx))) return rc;
-        if ((rc = rt_accumulate_impl(ctx, ctx->sampleCount, matte ? 1 : 0))) return rc;
-        ctx->sampleCount++;
-    }
+    if ((rc = rt_render_frames_impl(ctx, seeds, n_frames))) return rc;
     RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     float ms = 0;
@@ -346,10 +339,11 @@ uint32_t rt_local_pixel_count(RtContext *ctx) { return ctx && ctx->paramsSet ? c
 
 static float4 *image_ptr(RtContext *ctx, int which)
 {
+    const size_t off = (size_t)ctx->lastFrame * ctx->tile.nSlots;   // the newest frame of the last batch
     switch (which) {
-    case RT_IMAGE_RT: return ctx->dRt;
+    case RT_IMAGE_RT: return ctx->dRt ? ctx->dRt + off : nullptr;
     case RT_IMAGE_CONVERGED: return ctx->dConv;
-    case RT_IMAGE_SHADOWMAP: return ctx->dShadowMap;
+    case RT_IMAGE_SHADOWMAP: return ctx->dShadowMap ? ctx->dShadowMap + off : nullptr;
     default: return nullptr;
     }
 }

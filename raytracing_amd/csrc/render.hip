@@ -127,29 +127,37 @@ __global__ void k_pack_rays(const float *__restrict__ o3, const float *__restric
 
 // ------------------------------------------------------------------ wavefront kernels
 // CSMain prologue (RayTracing.compute:48-65): seed, jitter, camera ray.
-__global__ __launch_bounds__(256) void k_generate(RtTileMap tm, RtParams P, float4 *__restrict__ po, float4 *__restrict__ pd,
-                                                   float4 *__restrict__ pe, float4 *__restrict__ rt, uint2 *__restrict__ rng,
+// A launch covers `nFrames` consecutive frames of the same view: path slot
+// g = frame * nSlots + tile-local pixel slot, frame f uses seeds[f].  USE_DOF
+// selects which flag turns the lens camera on (CSMain: the RT_FLAG_DOF_PRIMARY
+// extension; ShadowMap: RT_FLAG_DEPTH_OF_FIELD as in the reference).
+template <uint32_t DOF_FLAG, bool CLEAR_RT>
+__global__ __launch_bounds__(256) void k_generate(RtTileMap tm, RtParams P, const float *__restrict__ seeds, uint32_t nFrames,
+                                                   float4 *__restrict__ po, float4 *__restrict__ pd, float4 *__restrict__ pe,
+                                                   float4 *__restrict__ img, uint2 *__restrict__ rng,
                                                    uint32_t *__restrict__ queue, uint32_t *__restrict__ qcount)
 {
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t total = tm.nSlots * nFrames;
+    const uint32_t frame = g / tm.nSlots, slot = g - frame * tm.nSlots;
     uint32_t px = 0, py = 0;
-    const bool active = slot < tm.nSlots && tm.slot_to_pixel(slot, &px, &py);
-    if (slot < tm.nSlots) rt[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const bool active = g < total && tm.slot_to_pixel(slot, &px, &py);
+    if (g < total && (CLEAR_RT || !active)) img[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (active) {
         rt_rng r;
-        rt_rng_init(&r, px, py, P.seed);
+        rt_rng_init(&r, px, py, seeds[frame]);
         const float r0 = rt_rand(&r), r1 = rt_rand(&r);
         const float uvx = (((float)px + r0) - 0.5f) / (float)P.width * 2 - 1;
         const float uvy = (((float)py + r1) - 0.5f) / (float)P.height * 2 - 1;
         rt_f3 o, d;
-        if (P.flags & RT_FLAG_DOF_PRIMARY) d_dof_camera_ray(P, r, uvx, uvy, o, d);
+        if (P.flags & DOF_FLAG) d_dof_camera_ray(P, r, uvx, uvy, o, d);
         else d_camera_ray(P, uvx, uvy, o, d);
-        po[slot] = make_float4(o.x, o.y, o.z, 0.0f);
-        pd[slot] = make_float4(d.x, d.y, d.z, 0.0f);
-        pe[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-        rng[slot] = make_uint2(r.state, __float_as_uint(r.seed));
+        po[g] = make_float4(o.x, o.y, o.z, 0.0f);
+        pd[g] = make_float4(d.x, d.y, d.z, 0.0f);
+        if (CLEAR_RT) pe[g] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        rng[g] = make_uint2(r.state, __float_as_uint(r.seed));
     }
-    queue_push(active, slot, queue, qcount);
+    queue_push(active, g, queue, qcount);
 }
 
 // Gathers what CheckTriangle copies into RayHit on an accepted hit
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(256) void k_shade(RtSceneView sv, RtTileMap tm, RtP
                 c.P = &P;
                 const uint2 rs = rng[slot];
                 uint32_t px, py;
-                tm.slot_to_pixel(slot, &px, &py);   // global pixel coordinates feed Rand()
+                tm.slot_to_pixel(slot % tm.nSlots, &px, &py);   // global pixel coordinates feed Rand()
                 c.rng.state = rs.x;
                 c.rng.seed = __uint_as_float(rs.y);
                 c.rng.px = (float)px;
@@ -256,30 +264,6 @@ __global__ __launch_bounds__(256) void k_shade(RtSceneView sv, RtTileMap tm, RtP
 // ------------------------------------------------------------------ ShadowMap pass (RayTracing.compute:96-131)
 // generate (primary ray, DoF-capable) -> traverse -> setup (hit point, disk
 // rotation) -> traverse 16 shadow rays per shaded pixel -> resolve.
-__global__ __launch_bounds__(256) void k_sm_generate(RtTileMap tm, RtParams P, float4 *__restrict__ po, float4 *__restrict__ pd,
-                                                      uint2 *__restrict__ rng, float4 *__restrict__ shadowMap,
-                                                      uint32_t *__restrict__ queue, uint32_t *__restrict__ qcount)
-{
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t px = 0, py = 0;
-    const bool active = slot < tm.nSlots && tm.slot_to_pixel(slot, &px, &py);
-    if (slot < tm.nSlots && !active) shadowMap[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (active) {
-        rt_rng r;
-        rt_rng_init(&r, px, py, P.seed);
-        const float r0 = rt_rand(&r), r1 = rt_rand(&r);
-        const float uvx = (((float)px + r0) - 0.5f) / (float)P.width * 2 - 1;
-        const float uvy = (((float)py + r1) - 0.5f) / (float)P.height * 2 - 1;
-        rt_f3 o, d;
-        if (P.flags & RT_FLAG_DEPTH_OF_FIELD) d_dof_camera_ray(P, r, uvx, uvy, o, d);
-        else d_camera_ray(P, uvx, uvy, o, d);
-        po[slot] = make_float4(o.x, o.y, o.z, 0.0f);
-        pd[slot] = make_float4(d.x, d.y, d.z, 0.0f);
-        rng[slot] = make_uint2(r.state, __float_as_uint(r.seed));
-    }
-    queue_push(active, slot, queue, qcount);
-}
-
 __global__ __launch_bounds__(256) void k_sm_setup(RtSceneView sv, RtTileMap tm, RtParams P, const uint32_t *__restrict__ queue,
                                                    const uint32_t *__restrict__ qcount, const float4 *__restrict__ po,
                                                    const float4 *__restrict__ pd, const uint2 *__restrict__ rng,
@@ -305,7 +289,7 @@ __global__ __launch_bounds__(256) void k_sm_setup(RtSceneView sv, RtTileMap tm, 
             const rt_f3 origin = rt_add3(hit.position, rt_scale3(hit.normal, RT_NORMAL_BIAS));
             rt_rng r;
             uint32_t px, py;
-            tm.slot_to_pixel(slot, &px, &py);
+            tm.slot_to_pixel(slot % tm.nSlots, &px, &py);
             const uint2 rs = rng[slot];
             r.state = rs.x;
             r.seed = __uint_as_float(rs.y);
@@ -344,21 +328,27 @@ __global__ __launch_bounds__(256) void k_sm_resolve(RtParams P, const uint32_t *
 
 // ------------------------------------------------------------------ accumulate
 // AddShader pass 0/1 under Blend SrcAlpha OneMinusSrcAlpha: dst = src*a + dst*(1-a),
-// a = 1/(n+1); the alpha channel blends src.a (= a) the same way.
-__global__ __launch_bounds__(256) void k_accumulate(uint32_t n, const float4 *__restrict__ rt, const float4 *__restrict__ shadowMap,
-                                                     float4 *__restrict__ conv, float samplePrePixel, int pass)
+// a = 1/(n+1); the alpha channel blends src.a (= a) the same way.  The frames of
+// a batch are folded in frame order, so the result is the one n successive
+// blits produce.
+__global__ __launch_bounds__(256) void k_accumulate(uint32_t nSlots, uint32_t nFrames, const float4 *__restrict__ rt,
+                                                     const float4 *__restrict__ shadowMap, float4 *__restrict__ conv,
+                                                     uint32_t samplePrePixel, int pass)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float4 c = rt[i];
-    if (pass == 1) {
-        const float4 s = shadowMap[i];
-        c.x *= s.x; c.y *= s.y; c.z *= s.z;
-    }
-    const float a = 1.0f / (samplePrePixel + 1.0f);
-    const float4 dst = conv[i];
-    conv[i] = make_float4(c.x * a + dst.x * (1.0f - a), c.y * a + dst.y * (1.0f - a), c.z * a + dst.z * (1.0f - a),
+    if (i >= nSlots) return;
+    float4 dst = conv[i];
+    for (uint32_t f = 0; f < nFrames; ++f) {
+        float4 c = rt[(size_t)f * nSlots + i];
+        if (pass == 1) {
+            const float4 sm = shadowMap[(size_t)f * nSlots + i];
+            c.x *= sm.x; c.y *= sm.y; c.z *= sm.z;
+        }
+        const float a = 1.0f / ((float)(samplePrePixel + f) + 1.0f);
+        dst = make_float4(c.x * a + dst.x * (1.0f - a), c.y * a + dst.y * (1.0f - a), c.z * a + dst.z * (1.0f - a),
                           a * a + dst.w * (1.0f - a));
+    }
+    conv[i] = dst;
 }
 
 __global__ void k_expand_local(RtTileMap tm, const float4 *__restrict__ local, float4 *__restrict__ full)
@@ -423,36 +413,48 @@ RtSceneView rt_scene_view(RtContext *ctx)
     return sv;
 }
 
-// Layout of the small counter block (dQCount), zeroed at the start of a frame:
-//   [0..8]  live-path counts of bounce 0..8      [9]  shaded pixels of the ShadowMap pass
+// Layout of the small counter block (dQCount), zeroed at the start of a batch:
+//   [0..8]  live-path counts of bounce 0..8      [9]  shaded pixels of the ShadowMap pass, [10] its primary rays
 //   [16..23] ray-fetch cursors of the 8 extend launches, [24]/[25] ShadowMap primary / shadow rays, [26] rt_trace_rays
 #define CNT_SMQ 9
+#define CNT_SMPRIM 10
 #define CNT_FETCH 16
 #define CNT_FETCH_SM0 24
 #define CNT_FETCH_SM1 25
 #define CNT_FETCH_TRACE 26
 #define CNT_WORDS 32
+#define RT_MAX_BATCH 8u
+#define RT_MAX_PATH_SLOTS (96u << 20)
 
 void rt_free_render(RtContext *ctx)
 {
     void **ptrs[] = {(void **)&ctx->dRt, (void **)&ctx->dConv, (void **)&ctx->dShadowMap, (void **)&ctx->dPo,
                      (void **)&ctx->dPd, (void **)&ctx->dPe, (void **)&ctx->dRng, (void **)&ctx->dHit,
-                     (void **)&ctx->dQueue[0], (void **)&ctx->dQueue[1], (void **)&ctx->dSmRec, (void **)&ctx->dSmFlags};
+                     (void **)&ctx->dQueue[0], (void **)&ctx->dQueue[1], (void **)&ctx->dSmQueue, (void **)&ctx->dSmRec,
+                     (void **)&ctx->dSmFlags, (void **)&ctx->dSeeds};
     for (void **p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
     ctx->allocSlots = 0;
+    ctx->batchCap = 0;
 }
 
-int rt_alloc_render(RtContext *ctx)
+// Path-state buffers for `frames` frames in flight; the accumulator stays one frame.
+static int alloc_batch(RtContext *ctx, uint32_t frames)
 {
     const uint32_t n = ctx->tile.nSlots;
-    if (n == ctx->allocSlots && ctx->dRt) return RT_OK;
-    rt_free_render(ctx);
-    const size_t m = n ? n : 1;
+    if (frames <= ctx->batchCap) return RT_OK;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    void **ptrs[] = {(void **)&ctx->dRt, (void **)&ctx->dShadowMap, (void **)&ctx->dPo, (void **)&ctx->dPd, (void **)&ctx->dPe,
+                     (void **)&ctx->dRng, (void **)&ctx->dHit, (void **)&ctx->dQueue[0], (void **)&ctx->dQueue[1],
+                     (void **)&ctx->dSmQueue, (void **)&ctx->dSmRec, (void **)&ctx->dSmFlags, (void **)&ctx->dSeeds};
+    for (void **p : ptrs) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    const size_t m = (size_t)(n ? n : 1) * frames;
     RT_HIP(ctx, hipMalloc((void **)&ctx->dRt, m * sizeof(float4)));
-    RT_HIP(ctx, hipMalloc((void **)&ctx->dConv, m * sizeof(float4)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dShadowMap, m * sizeof(float4)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dPo, m * sizeof(float4)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dPd, m * sizeof(float4)));
@@ -461,14 +463,38 @@ int rt_alloc_render(RtContext *ctx)
     RT_HIP(ctx, hipMalloc((void **)&ctx->dHit, m * sizeof(RtHitRec)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dQueue[0], m * sizeof(uint32_t)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dQueue[1], m * sizeof(uint32_t)));
+    RT_HIP(ctx, hipMalloc((void **)&ctx->dSmQueue, m * sizeof(uint32_t)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dSmRec, m * 2 * sizeof(float4)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dSmFlags, m * 16));
+    RT_HIP(ctx, hipMalloc((void **)&ctx->dSeeds, RT_MAX_BATCH * sizeof(float)));
     RT_HIP(ctx, hipMemsetAsync(ctx->dRt, 0, m * sizeof(float4), ctx->stream));
-    RT_HIP(ctx, hipMemsetAsync(ctx->dConv, 0, m * sizeof(float4), ctx->stream));
     RT_HIP(ctx, hipMemsetAsync(ctx->dShadowMap, 0, m * sizeof(float4), ctx->stream));
+    ctx->batchCap = frames;
+    ctx->lastFrame = 0;
+    return RT_OK;
+}
+
+int rt_alloc_render(RtContext *ctx)
+{
+    const uint32_t n = ctx->tile.nSlots;
+    if (n == ctx->allocSlots && ctx->dConv) return RT_OK;
+    rt_free_render(ctx);
+    if (ctx->dConv) (void)hipFree(ctx->dConv);
+    ctx->dConv = nullptr;
+    const size_t m = n ? n : 1;
+    RT_HIP(ctx, hipMalloc((void **)&ctx->dConv, m * sizeof(float4)));
+    RT_HIP(ctx, hipMemsetAsync(ctx->dConv, 0, m * sizeof(float4), ctx->stream));
     ctx->allocSlots = n;
     ctx->sampleCount = 0;
-    return RT_OK;
+    return alloc_batch(ctx, 1);
+}
+
+uint32_t rt_batch_frames(RtContext *ctx, uint32_t wanted)
+{
+    const uint32_t n = ctx->tile.nSlots ? ctx->tile.nSlots : 1;
+    uint32_t f = wanted < RT_MAX_BATCH ? wanted : RT_MAX_BATCH;
+    while (f > 1 && (uint64_t)f * n > RT_MAX_PATH_SLOTS) --f;
+    return f ? f : 1;
 }
 
 // Persistent launch: enough resident waves to fill the chip; every wave pulls
@@ -486,17 +512,57 @@ static void launch_traverse(RtContext *ctx, const RtSceneView &sv, const Src &sr
     rt_timer_end(ctx);
 }
 
-int rt_dispatch_impl(RtContext *ctx)
+static bool shadow_shares_primary(const RtParams &P)
+{
+    // CSMain and ShadowMap draw the same two jitter numbers from the same seed; they trace the
+    // same primary ray whenever both use the same camera model (RayTracing.compute:58-65 vs 103-110).
+    return ((P.flags & RT_FLAG_DOF_PRIMARY) != 0) == ((P.flags & RT_FLAG_DEPTH_OF_FIELD) != 0);
+}
+
+static void launch_sm_setup(RtContext *ctx, const RtSceneView &sv, uint32_t total, const uint32_t *queue, const uint32_t *qcount)
+{
+    rt_timer_begin(ctx, "k_sm_setup");
+    hipLaunchKernelGGL(k_sm_setup, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, sv, ctx->tile, ctx->params, queue, qcount,
+                       ctx->dPo, ctx->dPd, ctx->dRng, ctx->dHit, ctx->dSmRec, ctx->dShadowMap, ctx->dSmQueue, ctx->dQCount + CNT_SMQ);
+    rt_timer_end(ctx);
+}
+
+// 16 shadow rays per shaded pixel + the running mean (needs dSmQueue / dSmRec filled by k_sm_setup).
+static void launch_shadow_rays(RtContext *ctx, const RtSceneView &sv, uint32_t total)
+{
+    const RtParams &P = ctx->params;
+    ShadowSrc sh;
+    sh.smq = ctx->dSmQueue;
+    sh.smqCount = ctx->dQCount + CNT_SMQ;
+    sh.rec = ctx->dSmRec;
+    sh.flags = ctx->dSmFlags;
+    sh.leafShade = ctx->dLeafShade;
+    // Shadow.cginc:92-93, evaluated once on the host with the same IEEE float operations
+    sh.lightDir = rt_mk3(-P.lightParameter[0], -P.lightParameter[1], -P.lightParameter[2]);
+    sh.lightTangent = rt_normalize3(rt_cross3(sh.lightDir, rt_mk3(0.0f, 1.0f, 0.0f)));
+    sh.lightBitangent = rt_normalize3(rt_cross3(sh.lightTangent, sh.lightDir));
+    sh.lightRadius = P.lightParameter[3];
+    launch_traverse(ctx, sv, sh, ctx->dQCount + CNT_FETCH_SM1, total * 16u, "k_shadow_rays");
+    rt_timer_begin(ctx, "k_sm_resolve");
+    hipLaunchKernelGGL(k_sm_resolve, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, P, ctx->dSmQueue, ctx->dQCount + CNT_SMQ,
+                       ctx->dSmRec, ctx->dSmFlags, ctx->dShadowMap);
+    rt_timer_end(ctx);
+}
+
+// CSMain for `frames` frames of the current view (seeds already in dSeeds).
+// withShadowSetup: also prepare the ShadowMap pass from CSMain's own primary hits.
+static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup)
 {
     const uint32_t n = ctx->tile.nSlots;
     if (n == 0) return RT_OK;
+    const uint32_t total = n * frames;
     hipStream_t st = ctx->stream;
     const RtSceneView sv = rt_scene_view(ctx);
-    const dim3 blk(256), grid((n + 255) / 256);
+    const dim3 blk(256), grid((total + 255) / 256);
     RT_HIP(ctx, hipMemsetAsync(ctx->dQCount, 0, CNT_WORDS * sizeof(uint32_t), st));
     rt_timer_begin(ctx, "k_generate");
-    hipLaunchKernelGGL(k_generate, grid, blk, 0, st, ctx->tile, ctx->params, ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt,
-                       ctx->dRng, ctx->dQueue[0], ctx->dQCount);
+    hipLaunchKernelGGL((k_generate<RT_FLAG_DOF_PRIMARY, true>), grid, blk, 0, st, ctx->tile, ctx->params, ctx->dSeeds, frames,
+                       ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt, ctx->dRng, ctx->dQueue[0], ctx->dQCount);
     rt_timer_end(ctx);
     for (int b = 0; b < RT_MAX_BOUNCE; ++b) {
         uint32_t *qin = ctx->dQueue[b & 1], *qout = ctx->dQueue[(b + 1) & 1];
@@ -506,58 +572,75 @@ int rt_dispatch_impl(RtContext *ctx)
         src.po = ctx->dPo;
         src.pd = ctx->dPd;
         src.hit = ctx->dHit;
-        launch_traverse(ctx, sv, src, ctx->dQCount + CNT_FETCH + b, n, "k_extend");
+        launch_traverse(ctx, sv, src, ctx->dQCount + CNT_FETCH + b, total, "k_extend");
+        if (b == 0 && withShadowSetup) launch_sm_setup(ctx, sv, total, qin, ctx->dQCount);   // before shade moves the rays on
         rt_timer_begin(ctx, "k_shade");
         hipLaunchKernelGGL(k_shade, grid, blk, 0, st, sv, ctx->tile, ctx->params, b, qin, ctx->dQCount + b, qout, ctx->dQCount + b + 1,
                            ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
         rt_timer_end(ctx);
     }
+    ctx->lastFrame = frames - 1;
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }
 
-int rt_shadowmap_impl(RtContext *ctx)
+// The ShadowMap kernel's own primary rays (used when its camera differs from CSMain's, or stand-alone).
+static int shadowmap_frames(RtContext *ctx, uint32_t frames)
 {
     const uint32_t n = ctx->tile.nSlots;
     if (n == 0) return RT_OK;
+    const uint32_t total = n * frames;
     hipStream_t st = ctx->stream;
     const RtSceneView sv = rt_scene_view(ctx);
-    const RtParams &P = ctx->params;
-    const dim3 blk(256), grid((n + 255) / 256);
     uint32_t *cnt = ctx->dQCount;
     // the path-state buffers of CSMain are free again at this point and are reused
-    RT_HIP(ctx, hipMemsetAsync(cnt, 0, sizeof(uint32_t), st));
-    RT_HIP(ctx, hipMemsetAsync(cnt + CNT_SMQ, 0, sizeof(uint32_t), st));
+    RT_HIP(ctx, hipMemsetAsync(cnt + CNT_SMQ, 0, 2 * sizeof(uint32_t), st));
     RT_HIP(ctx, hipMemsetAsync(cnt + CNT_FETCH_SM0, 0, 2 * sizeof(uint32_t), st));
     rt_timer_begin(ctx, "k_sm_generate");
-    hipLaunchKernelGGL(k_sm_generate, grid, blk, 0, st, ctx->tile, P, ctx->dPo, ctx->dPd, ctx->dRng, ctx->dShadowMap,
-                       ctx->dQueue[0], cnt);
+    hipLaunchKernelGGL((k_generate<RT_FLAG_DEPTH_OF_FIELD, false>), dim3((total + 255) / 256), dim3(256), 0, st, ctx->tile, ctx->params,
+                       ctx->dSeeds, frames, ctx->dPo, ctx->dPd, ctx->dPe, ctx->dShadowMap, ctx->dRng, ctx->dQueue[0], cnt + CNT_SMPRIM);
     rt_timer_end(ctx);
     QueueSrc prim;
     prim.queue = ctx->dQueue[0];
-    prim.qcount = cnt;
+    prim.qcount = cnt + CNT_SMPRIM;
     prim.po = ctx->dPo;
     prim.pd = ctx->dPd;
     prim.hit = ctx->dHit;
-    launch_traverse(ctx, sv, prim, cnt + CNT_FETCH_SM0, n, "k_extend");
-    rt_timer_begin(ctx, "k_sm_setup");
-    hipLaunchKernelGGL(k_sm_setup, grid, blk, 0, st, sv, ctx->tile, P, ctx->dQueue[0], cnt, ctx->dPo, ctx->dPd, ctx->dRng, ctx->dHit,
-                       ctx->dSmRec, ctx->dShadowMap, ctx->dQueue[1], cnt + CNT_SMQ);
-    rt_timer_end(ctx);
-    ShadowSrc sh;
-    sh.smq = ctx->dQueue[1];
-    sh.smqCount = cnt + CNT_SMQ;
-    sh.rec = ctx->dSmRec;
-    sh.flags = ctx->dSmFlags;
-    sh.leafShade = ctx->dLeafShade;
-    // Shadow.cginc:92-93, evaluated once on the host with the same IEEE float operations
-    sh.lightDir = rt_mk3(-P.lightParameter[0], -P.lightParameter[1], -P.lightParameter[2]);
-    sh.lightTangent = rt_normalize3(rt_cross3(sh.lightDir, rt_mk3(0.0f, 1.0f, 0.0f)));
-    sh.lightBitangent = rt_normalize3(rt_cross3(sh.lightTangent, sh.lightDir));
-    sh.lightRadius = P.lightParameter[3];
-    launch_traverse(ctx, sv, sh, cnt + CNT_FETCH_SM1, n * 16u, "k_shadow_rays");
-    rt_timer_begin(ctx, "k_sm_resolve");
-    hipLaunchKernelGGL(k_sm_resolve, grid, blk, 0, st, P, ctx->dQueue[1], cnt + CNT_SMQ, ctx->dSmRec, ctx->dSmFlags, ctx->dShadowMap);
+    launch_traverse(ctx, sv, prim, cnt + CNT_FETCH_SM0, total, "k_extend");
+    launch_sm_setup(ctx, sv, total, ctx->dQueue[0], cnt + CNT_SMPRIM);
+    launch_shadow_rays(ctx, sv, total);
+    RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+static int upload_seeds(RtContext *ctx, const float *seeds, uint32_t n)
+{
+    RT_HIP(ctx, hipMemcpyAsync(ctx->dSeeds, seeds, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    return RT_OK;
+}
+
+int rt_dispatch_impl(RtContext *ctx)
+{
+    int rc = upload_seeds(ctx, &ctx->params.seed, 1);
+    if (rc) return rc;
+    return dispatch_frames(ctx, 1, false);
+}
+
+int rt_shadowmap_impl(RtContext *ctx)
+{
+    int rc = upload_seeds(ctx, &ctx->params.seed, 1);
+    if (rc) return rc;
+    ctx->lastFrame = 0;
+    return shadowmap_frames(ctx, 1);
+}
+
+static int accumulate_frames(RtContext *ctx, uint32_t frames, uint32_t samplePerPixel, int useShadowMap, size_t frameOffset)
+{
+    const uint32_t n = ctx->tile.nSlots;
+    if (n == 0) return RT_OK;
+    rt_timer_begin(ctx, "k_accumulate");
+    hipLaunchKernelGGL(k_accumulate, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, frames, ctx->dRt + frameOffset * n,
+                       ctx->dShadowMap + frameOffset * n, ctx->dConv, samplePerPixel, useShadowMap ? 1 : 0);
     rt_timer_end(ctx);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
@@ -565,13 +648,29 @@ int rt_shadowmap_impl(RtContext *ctx)
 
 int rt_accumulate_impl(RtContext *ctx, uint32_t samplePerPixel, int useShadowMap)
 {
-    const uint32_t n = ctx->tile.nSlots;
-    if (n == 0) return RT_OK;
-    rt_timer_begin(ctx, "k_accumulate");
-    hipLaunchKernelGGL(k_accumulate, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, ctx->dRt, ctx->dShadowMap, ctx->dConv,
-                       (float)samplePerPixel, useShadowMap ? 1 : 0);
-    rt_timer_end(ctx);
-    RT_HIP(ctx, hipGetLastError());
+    return accumulate_frames(ctx, 1, samplePerPixel, useShadowMap, ctx->lastFrame);
+}
+
+// n x CustomRender, `batch` frames in flight at a time.
+int rt_render_frames_impl(RtContext *ctx, const float *seeds, uint32_t nFrames)
+{
+    const bool matte = (ctx->params.flags & RT_FLAG_MATTE_MASK) != 0;
+    const bool shared = matte && shadow_shares_primary(ctx->params);
+    const uint32_t batch = rt_batch_frames(ctx, nFrames);
+    int rc = alloc_batch(ctx, batch);
+    if (rc) return rc;
+    for (uint32_t base = 0; base < nFrames; base += batch) {
+        const uint32_t f = nFrames - base < batch ? nFrames - base : batch;
+        if ((rc = upload_seeds(ctx, seeds + base, f))) return rc;
+        if ((rc = dispatch_frames(ctx, f, shared))) return rc;
+        if (matte) {
+            if (shared) launch_shadow_rays(ctx, rt_scene_view(ctx), ctx->tile.nSlots * f);
+            else if ((rc = shadowmap_frames(ctx, f))) return rc;
+        }
+        if ((rc = accumulate_frames(ctx, f, ctx->sampleCount, matte ? 1 : 0, 0))) return rc;
+        ctx->sampleCount += f;
+        ctx->params.seed = seeds[base + f - 1];
+    }
     return RT_OK;
 }
 

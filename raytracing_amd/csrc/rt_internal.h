@@ -148,6 +148,10 @@ struct RtContext {
     RtHitRec *dHit = nullptr;
     uint32_t *dQueue[2] = {nullptr, nullptr};
     uint32_t *dQCount = nullptr;          // 32-word counter block, owned by the context
+    uint32_t *dSmQueue = nullptr;         // ShadowMap pass: shaded path slots
+    float *dSeeds = nullptr;              // per-frame seeds of the batch in flight
+    uint32_t batchCap = 0;                // frames the path-state buffers can hold
+    uint32_t lastFrame = 0;               // frame of the batch that RT_IMAGE_RT / RT_IMAGE_SHADOWMAP show
     float4 *dSmRec = nullptr;             // ShadowMap pass: 2 x float4 per slot
     uint8_t *dSmFlags = nullptr;          // ShadowMap pass: 16 results per slot
     int numCU = 256;
@@ -191,6 +195,7 @@ void rt_free_render(RtContext *ctx);
 int rt_dispatch_impl(RtContext *ctx);
 int rt_shadowmap_impl(RtContext *ctx);
 int rt_accumulate_impl(RtContext *ctx, uint32_t samplePerPixel, int useShadowMap);
+int rt_render_frames_impl(RtContext *ctx, const float *seeds, uint32_t nFrames);
 int rt_trace_device_impl(RtContext *ctx, const float4 *o, const float4 *d, uint32_t n, RtHitRec *hits);
 int rt_expand_local_impl(RtContext *ctx, const float4 *local, float4 *full);
 int rt_pack_rays_impl(RtContext *ctx, const float *o3, const float *d3, uint32_t n, float4 *o4, float4 *d4);

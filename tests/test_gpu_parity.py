@@ -196,6 +196,36 @@ def test_manual_dispatch_accumulate_equals_render_frames(core):
     H.assert_bits_equal(a, b, "render_frames vs dispatch+accumulate")
 
 
+@pytest.mark.parametrize("flags_clear", [0, wire.FLAG_DOF_PRIMARY, wire.FLAG_DOF_PRIMARY | wire.FLAG_DEPTH_OF_FIELD])
+def test_batched_frames_equal_frame_by_frame_driver(core, flags_clear):
+    """rt_render_frames keeps several frames in flight (and lets the ShadowMap pass reuse CSMain's
+    primary hits when both use the same camera); the image must be the one CustomRender produces
+    frame by frame (RayTracing.cs:118-164): CSMain, ShadowMap, Blit."""
+    sc = scenes.car_standin(72, 40, detail=0.02)
+    p = sc.params.copy()
+    p.flags &= ~flags_clear
+    seeds = scenes.frame_seeds(11, seed=9)        # one full batch and a ragged one
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(p)
+    core.set_dirty()
+    core.render_frames(seeds)
+    a = core.readback(wire.IMAGE_CONVERGED)
+    a_rt = core.readback(wire.IMAGE_RT)
+    a_sm = core.readback(wire.IMAGE_SHADOWMAP)
+    assert core.sample_count == 11
+    core.set_dirty()
+    for k, s in enumerate(seeds):
+        p.seed = float(s)
+        core.set_params(p)
+        core.dispatch()
+        core.dispatch_shadowmap()
+        core.accumulate(k, True)
+    H.assert_bits_equal(a, core.readback(wire.IMAGE_CONVERGED), "batched vs frame-by-frame")
+    H.assert_bits_equal(a_rt, core.readback(wire.IMAGE_RT), "last frame of the batch")
+    H.assert_bits_equal(a_sm, core.readback(wire.IMAGE_SHADOWMAP), "last shadow map of the batch")
+
+
 def test_tiles_union_is_bit_identical_to_whole_frame(core):
     sc = scenes.cornell_box(200, 136, sphere_segments=16)     # not a multiple of the tile size
     seeds = scenes.frame_seeds(2, seed=6)
