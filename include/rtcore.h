@@ -237,6 +237,21 @@ int rt_trace_rays_device(RtContext *ctx, const void *device_origins4, const void
  * pixel (x[0],x[1]) with seed y[0], Header.cginc:79-92).  No reference counterpart. */
 int rt_debug_eval(RtContext *ctx, int which, const float *x, const float *y, uint32_t n, float *out);
 
+/* ------------------------------------------------------------------ tuning */
+/* Execution knobs; none changes a result bit.  No reference counterpart (the
+ * reference has one fixed schedule: a thread per pixel, a dispatch per frame).
+ *   RT_OPT_PACKET_SHADOW   0 (default): 1 = the 16 soft-shadow rays of a pixel walk the tree as one packet
+ *   RT_OPT_PACKET_PRIMARY  0 (default): 1 = camera rays walk the tree in packets of 16 neighbouring pixels
+ *   RT_OPT_PACKET_TRACE    0 (default): 1 = rt_trace_rays walks caller rays 16 at a time
+ * (packets pay off only where the 16 rays stay inside the same few leaves; on finely
+ *  tessellated scenes the one-ray-per-lane walker is about twice as fast)
+ *   RT_OPT_BATCH_FRAMES    1..8 (default 8): frames rt_render_frames keeps in flight */
+#define RT_OPT_PACKET_SHADOW 0
+#define RT_OPT_PACKET_PRIMARY 1
+#define RT_OPT_PACKET_TRACE 2
+#define RT_OPT_BATCH_FRAMES 3
+int rt_set_option(RtContext *ctx, int option, int value);
+
 /* ------------------------------------------------------------------- stats */
 /* When enabled, traversal kernels count node/leaf/triangle tests (slower). */
 int rt_enable_counters(RtContext *ctx, int enable);

@@ -484,6 +484,21 @@ int rt_debug_eval(RtContext *ctx, int which, const float *x, const float *y, uin
     return RT_OK;
 }
 
+int rt_set_option(RtContext *ctx, int option, int value)
+{
+    if (!ctx) return RT_E_INVALID;
+    switch (option) {
+    case RT_OPT_PACKET_SHADOW: ctx->optPacketShadow = value != 0; return RT_OK;
+    case RT_OPT_PACKET_PRIMARY: ctx->optPacketPrimary = value != 0; return RT_OK;
+    case RT_OPT_PACKET_TRACE: ctx->optPacketTrace = value != 0; return RT_OK;
+    case RT_OPT_BATCH_FRAMES:
+        if (value < 1 || value > 8) return rt_fail(ctx, RT_E_INVALID, "RT_OPT_BATCH_FRAMES must be 1..8");
+        ctx->optBatchFrames = (uint32_t)value;
+        return RT_OK;
+    default: return rt_fail(ctx, RT_E_INVALID, "unknown option");
+    }
+}
+
 int rt_enable_counters(RtContext *ctx, int enable)
 {
     if (!ctx) return RT_E_INVALID;

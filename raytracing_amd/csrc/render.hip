@@ -105,6 +105,13 @@ __global__ __launch_bounds__(TRV_THREADS) void k_traverse(RtSceneView sv, Src sr
     traverse_rays<COUNT>(sv, src, fetchCounter, lds);
 }
 
+template <bool COUNT, class Src>
+__global__ __launch_bounds__(TRV_THREADS) void k_traverse_packets(RtSceneView sv, Src src, uint32_t *__restrict__ fetchCounter)
+{
+    __shared__ uint32_t lds[PKT_LDS_WORDS];
+    traverse_packets<COUNT>(sv, src, fetchCounter, lds);
+}
+
 __global__ void k_unpack_hits(RtSceneView sv, const RtHitRec *__restrict__ hits, uint32_t n, float *t, uint32_t *tri,
                               float *u, float *v)
 {
@@ -492,7 +499,8 @@ int rt_alloc_render(RtContext *ctx)
 uint32_t rt_batch_frames(RtContext *ctx, uint32_t wanted)
 {
     const uint32_t n = ctx->tile.nSlots ? ctx->tile.nSlots : 1;
-    uint32_t f = wanted < RT_MAX_BATCH ? wanted : RT_MAX_BATCH;
+    const uint32_t cap = ctx->optBatchFrames < RT_MAX_BATCH ? ctx->optBatchFrames : RT_MAX_BATCH;
+    uint32_t f = wanted < cap ? wanted : cap;
     while (f > 1 && (uint64_t)f * n > RT_MAX_PATH_SLOTS) --f;
     return f ? f : 1;
 }
@@ -509,6 +517,29 @@ static void launch_traverse(RtContext *ctx, const RtSceneView &sv, const Src &sr
     rt_timer_begin(ctx, name);
     if (ctx->countersOn) hipLaunchKernelGGL((k_traverse<true, Src>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, src, fetchCounter);
     else hipLaunchKernelGGL((k_traverse<false, Src>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, src, fetchCounter);
+    rt_timer_end(ctx);
+}
+
+// Same contract, rays walked 16 at a time (coherent sources only: correct for any rays, fast for coherent ones).
+template <class Src>
+static void launch_traverse_packets(RtContext *ctx, const RtSceneView &sv, const Src &src, uint32_t *fetchCounter, uint32_t maxRays,
+                                    const char *name)
+{
+    static int perCU[2] = {0, 0};
+    const int ci = ctx->countersOn ? 1 : 0;
+    if (perCU[ci] == 0) {
+        int n = 0;
+        hipError_t e = ctx->countersOn
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_packets<true, Src>, TRV_THREADS, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_packets<false, Src>, TRV_THREADS, 0);
+        perCU[ci] = (e == hipSuccess && n > 0) ? n : 4;
+    }
+    uint32_t blocks = (uint32_t)ctx->numCU * (uint32_t)perCU[ci];
+    const uint32_t need = (maxRays + TRV_THREADS - 1) / TRV_THREADS;
+    if (need < blocks) blocks = need ? need : 1;
+    rt_timer_begin(ctx, name);
+    if (ctx->countersOn) hipLaunchKernelGGL((k_traverse_packets<true, Src>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, src, fetchCounter);
+    else hipLaunchKernelGGL((k_traverse_packets<false, Src>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, src, fetchCounter);
     rt_timer_end(ctx);
 }
 
@@ -542,7 +573,8 @@ static void launch_shadow_rays(RtContext *ctx, const RtSceneView &sv, uint32_t t
     sh.lightTangent = rt_normalize3(rt_cross3(sh.lightDir, rt_mk3(0.0f, 1.0f, 0.0f)));
     sh.lightBitangent = rt_normalize3(rt_cross3(sh.lightTangent, sh.lightDir));
     sh.lightRadius = P.lightParameter[3];
-    launch_traverse(ctx, sv, sh, ctx->dQCount + CNT_FETCH_SM1, total * 16u, "k_shadow_rays");
+    if (ctx->optPacketShadow) launch_traverse_packets(ctx, sv, sh, ctx->dQCount + CNT_FETCH_SM1, total * 16u, "k_shadow_rays");
+    else launch_traverse(ctx, sv, sh, ctx->dQCount + CNT_FETCH_SM1, total * 16u, "k_shadow_rays");
     rt_timer_begin(ctx, "k_sm_resolve");
     hipLaunchKernelGGL(k_sm_resolve, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, P, ctx->dSmQueue, ctx->dQCount + CNT_SMQ,
                        ctx->dSmRec, ctx->dSmFlags, ctx->dShadowMap);
@@ -572,7 +604,8 @@ static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup
         src.po = ctx->dPo;
         src.pd = ctx->dPd;
         src.hit = ctx->dHit;
-        launch_traverse(ctx, sv, src, ctx->dQCount + CNT_FETCH + b, total, "k_extend");
+        if (b == 0 && ctx->optPacketPrimary) launch_traverse_packets(ctx, sv, src, ctx->dQCount + CNT_FETCH + b, total, "k_extend");
+        else launch_traverse(ctx, sv, src, ctx->dQCount + CNT_FETCH + b, total, "k_extend");
         if (b == 0 && withShadowSetup) launch_sm_setup(ctx, sv, total, qin, ctx->dQCount);   // before shade moves the rays on
         rt_timer_begin(ctx, "k_shade");
         hipLaunchKernelGGL(k_shade, grid, blk, 0, st, sv, ctx->tile, ctx->params, b, qin, ctx->dQCount + b, qout, ctx->dQCount + b + 1,
@@ -606,7 +639,8 @@ static int shadowmap_frames(RtContext *ctx, uint32_t frames)
     prim.po = ctx->dPo;
     prim.pd = ctx->dPd;
     prim.hit = ctx->dHit;
-    launch_traverse(ctx, sv, prim, cnt + CNT_FETCH_SM0, total, "k_extend");
+    if (ctx->optPacketPrimary) launch_traverse_packets(ctx, sv, prim, cnt + CNT_FETCH_SM0, total, "k_extend");
+    else launch_traverse(ctx, sv, prim, cnt + CNT_FETCH_SM0, total, "k_extend");
     launch_sm_setup(ctx, sv, total, ctx->dQueue[0], cnt + CNT_SMPRIM);
     launch_shadow_rays(ctx, sv, total);
     RT_HIP(ctx, hipGetLastError());
@@ -684,7 +718,8 @@ int rt_trace_device_impl(RtContext *ctx, const float4 *o, const float4 *d, uint3
     src.dir = d;
     src.n = n;
     src.hits = hits;
-    launch_traverse(ctx, sv, src, ctx->dQCount + CNT_FETCH_TRACE, n, "k_trace");
+    if (ctx->optPacketTrace) launch_traverse_packets(ctx, sv, src, ctx->dQCount + CNT_FETCH_TRACE, n, "k_trace");
+    else launch_traverse(ctx, sv, src, ctx->dQCount + CNT_FETCH_TRACE, n, "k_trace");
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }

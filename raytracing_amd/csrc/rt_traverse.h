@@ -218,4 +218,181 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
     if (COUNT) flush_counters(sv, nRays, cnt, nHits);
 }
 
+// ---------------------------------------------------------------------------
+// Packet traversal: 16 consecutive rays of the source (rays 16k .. 16k+15) walk
+// the tree together in one quarter of a wave.  It is meant for rays that start
+// close together and point the same way (the 16 soft-shadow rays of a pixel,
+// camera rays of neighbouring pixels): the packet fetches a node once, with one
+// coalesced 64-byte read spread over its 16 lanes, and hands the words round
+// with row-broadcast DPP moves, instead of 16 lanes each fetching 64 bytes.
+//
+// Every ray still takes exactly the decisions of its own traversal: a stack
+// entry carries the 16-bit set of rays whose own box test let them into that
+// node, a ray tests a child box or a triangle only where it is in the set, and
+// the packet walks the tree in the reference's depth-first order, so each ray
+// meets its candidates in the order its own walk would (strict '<' keeps the
+// first).  The packet only adds node visits that some other ray of the packet
+// needed.
+#define PKT_WIDTH 16u
+#define PKT_STACK_WORDS (2 * RT_STACK_DEPTH)                       // (node, ray set) per level
+#define PKT_LDS_WORDS (PKT_STACK_WORDS * (TRV_THREADS / PKT_WIDTH))
+
+template <int J>
+__device__ __forceinline__ uint32_t row_bcast(uint32_t x)           // lane J of each 16-lane row -> the whole row
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 + J, 0xF, 0xF, false);
+}
+template <int J>
+__device__ __forceinline__ float row_bcastf(uint32_t x) { return __uint_as_float(row_bcast<J>(x)); }
+
+// 16-bit ballot of this lane's row (all 16 lanes of the row must be active)
+__device__ __forceinline__ uint32_t row_ballot(bool p, uint32_t rowShift)
+{
+    return (uint32_t)(__ballot(p) >> rowShift) & 0xFFFFu;
+}
+
+__device__ __forceinline__ void tri_test_values(const rt_f3 v0, const rt_f3 e1, const rt_f3 e2, uint32_t leaf, const rt_f3 o,
+                                                const rt_f3 d, RtHitRec &h)
+{
+    const rt_f3 pvec = rt_cross3(d, e2);
+    const float det = rt_dot3(e1, pvec);
+    if (det < RT_EPSILON) return;
+    const float inv_det = 1.0f / det;
+    const rt_f3 tvec = rt_sub3(o, v0);
+    const float u = rt_dot3(tvec, pvec) * inv_det;
+    if (u < 0.0f || u > 1.0f) return;
+    const rt_f3 qvec = rt_cross3(tvec, e1);
+    const float v = rt_dot3(d, qvec) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return;
+    const float t = rt_dot3(e2, qvec) * inv_det;
+    if (t > 0.0f && t < h.t) {
+        h.t = t;
+        h.u = u;
+        h.v = v;
+        h.leaf = leaf;
+    }
+}
+
+// the packet's rays in `want` test sorted leaf `leaf`
+__device__ __forceinline__ void tri_test_packet(const RtSceneView &sv, uint32_t leaf, bool want, uint32_t sub, const rt_f3 o,
+                                                const rt_f3 d, RtHitRec &h)
+{
+    const uint32_t w = ((const uint32_t *)(sv.leafTri + leaf))[sub < 9u ? sub : 8u];   // v0, e1, e2: 36 bytes
+    const rt_f3 v0 = rt_mk3(row_bcastf<0>(w), row_bcastf<1>(w), row_bcastf<2>(w));
+    const rt_f3 e1 = rt_mk3(row_bcastf<3>(w), row_bcastf<4>(w), row_bcastf<5>(w));
+    const rt_f3 e2 = rt_mk3(row_bcastf<6>(w), row_bcastf<7>(w), row_bcastf<8>(w));
+    if (want) tri_test_values(v0, e1, e2, leaf, o, d, h);
+}
+
+// lds: PKT_LDS_WORDS words per block.
+template <bool COUNT, class Src>
+__device__ __forceinline__ void traverse_packets(const RtSceneView &sv, Src &src, uint32_t *__restrict__ fetchCounter, uint32_t *lds)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t sub = lane & 15u, rowShift = lane & 48u;
+    uint32_t *stk = lds + (threadIdx.x >> 4) * PKT_STACK_WORDS;
+    const uint32_t total = src.count();
+
+    // packet state (the same value in all 16 lanes of a row)
+    uint32_t node = TRV_DONE, set = 0, sp = 0;
+    bool exhausted = false;
+    // ray state
+    bool hasRay = false;
+    uint32_t rayIdx = 0;
+    rt_f3 o = rt_splat3(0.0f), d = rt_splat3(0.0f), r = rt_splat3(0.0f);
+    RtHitRec h;
+    h.t = rt_inf(); h.u = 0.0f; h.v = 0.0f; h.leaf = RT_INVALID;
+    uint32_t cnt[3] = {0, 0, 0};
+    uint32_t nRays = 0, nHits = 0;
+
+    for (;;) {
+        if (node == TRV_DONE && !exhausted) {
+            // ---- retire the finished packet, fetch the next one
+            if (hasRay) {
+                src.store(rayIdx, h);
+                if (COUNT && h.leaf != RT_INVALID) nHits++;
+                hasRay = false;
+            }
+            uint32_t base = 0;
+            if (sub == 0) base = atomicAdd(fetchCounter, PKT_WIDTH);
+            base = row_bcast<0>(base);
+            if (base >= total) {
+                exhausted = true;
+            } else {
+                rayIdx = base + sub;
+                hasRay = rayIdx < total;
+                sp = 0;
+                bool in = false;
+                if (hasRay) {
+                    src.load(rayIdx, o, d);
+                    r = rt_mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    h.t = rt_inf(); h.u = 0.0f; h.v = 0.0f; h.leaf = RT_INVALID;
+                    if (COUNT) nRays++;
+                    if (sv.nTriangles != 0) {
+                        if (COUNT) cnt[0]++;
+                        const RtAABB &rb = sv.rootBox;
+                        in = sv.nTriangles >= 2 && box_hit(rb.min[0], rb.min[1], rb.min[2], rb.max[0], rb.max[1], rb.max[2], o, d, r);
+                    }
+                }
+                set = row_ballot(in, rowShift);
+                node = set ? 0u : TRV_DONE;
+            }
+        }
+        if (__ballot(node != TRV_DONE || !exhausted) == 0ull) break;
+
+        if (node != TRV_DONE) {
+            // ---- one node for the whole packet: 16 lanes x 4 bytes, then row broadcasts
+            const uint32_t w = ((const uint32_t *)(sv.nodes + node))[sub];
+            const uint32_t l = row_bcast<12>(w), rr = row_bcast<13>(w);
+            const bool lLeaf = (l & RT_LEAF_BIT) != 0, rLeaf = (rr & RT_LEAF_BIT) != 0;
+            const bool act = hasRay && ((set >> sub) & 1u) != 0;
+            bool hitL = false, hitR = false;
+            {
+                const float a0 = row_bcastf<0>(w), a1 = row_bcastf<1>(w), a2 = row_bcastf<2>(w);
+                const float a3 = row_bcastf<3>(w), a4 = row_bcastf<4>(w), a5 = row_bcastf<5>(w);
+                const float b0 = row_bcastf<6>(w), b1 = row_bcastf<7>(w), b2 = row_bcastf<8>(w);
+                const float b3 = row_bcastf<9>(w), b4 = row_bcastf<10>(w), b5 = row_bcastf<11>(w);
+                if (act) {
+                    hitL = box_hit(a0, a1, a2, a3, a4, a5, o, d, r);
+                    hitR = box_hit(b0, b1, b2, b3, b4, b5, o, d, r);
+                }
+            }
+            if (COUNT && act) {
+                cnt[0] += (lLeaf ? 0u : 1u) + (rLeaf ? 0u : 1u);
+                cnt[1] += (lLeaf ? 1u : 0u) + (rLeaf ? 1u : 0u);
+                cnt[2] += ((lLeaf && hitL) ? 1u : 0u) + ((rLeaf && hitR) ? 1u : 0u);
+            }
+            const uint32_t setL = row_ballot(hitL, rowShift), setR = row_ballot(hitR, rowShift);
+            if (lLeaf && setL) tri_test_packet(sv, l & ~RT_LEAF_BIT, hitL, sub, o, d, h);
+            if (rLeaf && setR) tri_test_packet(sv, rr & ~RT_LEAF_BIT, hitR, sub, o, d, h);
+            const bool goL = !lLeaf && setL, goR = !rLeaf && setR;
+            if (goR) {
+                if (goL) {
+                    if (sp >= RT_STACK_DEPTH) { *sv.errorFlag = 1u; node = TRV_DONE; }
+                    else {
+                        stk[2 * sp] = l;           // all 16 lanes store the same two words
+                        stk[2 * sp + 1] = setL;
+                        sp++;
+                        node = rr;
+                        set = setR;
+                    }
+                } else {
+                    node = rr;
+                    set = setR;
+                }
+            } else if (goL) {
+                node = l;
+                set = setL;
+            } else if (sp == 0) {
+                node = TRV_DONE;
+            } else {
+                sp--;
+                node = stk[2 * sp];
+                set = stk[2 * sp + 1];
+            }
+        }
+    }
+    if (COUNT) flush_counters(sv, nRays, cnt, nHits);
+}
+
 #endif

@@ -21,7 +21,7 @@ EXPORTS = [
     "rt_dispatch_shadowmap", "rt_accumulate", "rt_render_frames", "rt_set_dirty", "rt_sample_count", "rt_readback",
     "rt_readback_local_device", "rt_upload_converged", "rt_local_pixel_count", "rt_local_pixel_map", "rt_trace_rays",
     "rt_trace_rays_device", "rt_enable_counters", "rt_enable_kernel_timing", "rt_reset_stats", "rt_get_stats",
-    "rt_kernel_time", "rt_synchronize", "rt_version", "rt_debug_eval",
+    "rt_kernel_time", "rt_synchronize", "rt_version", "rt_debug_eval", "rt_set_option",
 ]
 
 _lib = None
@@ -201,6 +201,10 @@ class RtCore:
         out = np.zeros(n, np.float32)
         self._check(self.lib.rt_debug_eval(self.ctx, C.c_int(which), _p(x), _p(y), C.c_uint32(n), _p(out)))
         return out
+
+    # ---- tuning
+    def set_option(self, option, value):
+        self._check(self.lib.rt_set_option(self.ctx, C.c_int(int(option)), C.c_int(int(value))))
 
     # ---- stats
     def enable_counters(self, on=True):

@@ -71,8 +71,11 @@ def test_empty_scene(core):
     assert np.isinf(r["t"]).all() and (r["triangle"] == 0xFFFFFFFF).all()
 
 
+@pytest.mark.parametrize("packets", [False, True], ids=["single", "packets"])
 @pytest.mark.parametrize("name", ["cornell", "soup20k", "dups", "tiny1", "tiny2"])
-def test_first_hit_bit_exact(core, oracle, name):
+def test_first_hit_bit_exact(core, oracle, name, packets):
+    """Both walkers (a ray per lane; 16 rays per packet) must take every ray through exactly the
+    reference's decisions: same hit, same bits, same number of box and triangle tests."""
     sc = _scene(name)
     orc = oracle.Oracle(sc).build()
     core.upload(sc)
@@ -88,11 +91,16 @@ def test_first_hit_bit_exact(core, oracle, name):
     d3 = np.array([[0, 0, 1], [1, 0, 0], [0, -1, 0], [0, 0, 0], [np.nan, 0, 1], [0, 1e-30, 1]], np.float32)
     o = np.concatenate([o1, o2, o3])
     d = np.concatenate([d1, d2, d3])
+    core.set_option(wire.OPT_PACKET_TRACE, packets)
     core.enable_counters(True)
     core.reset_stats()
     got = core.trace_rays(o, d)
     st = core.stats()
     core.enable_counters(False)
+    got_plain = core.trace_rays(o, d)             # the build without counters is a different kernel
+    core.set_option(wire.OPT_PACKET_TRACE, False)
+    for k in ("triangle", "t", "u", "v"):
+        H.assert_bits_equal(got_plain[k], got[k], f"{k}: counting vs plain kernel")
     want = orc.trace(o, d)
     H.assert_bits_equal(got["triangle"], want["triangle"], "first-hit triangle id")
     H.assert_bits_equal(got["t"], want["t"], "hit distance")
@@ -224,6 +232,24 @@ def test_batched_frames_equal_frame_by_frame_driver(core, flags_clear):
     H.assert_bits_equal(a, core.readback(wire.IMAGE_CONVERGED), "batched vs frame-by-frame")
     H.assert_bits_equal(a_rt, core.readback(wire.IMAGE_RT), "last frame of the batch")
     H.assert_bits_equal(a_sm, core.readback(wire.IMAGE_SHADOWMAP), "last shadow map of the batch")
+
+
+def test_packet_walkers_do_not_change_a_bit(core):
+    sc = scenes.car_standin(96, 64, detail=0.02)
+    seeds = scenes.frame_seeds(3, seed=10)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(sc.params)
+    images = []
+    for on in (1, 0):
+        core.set_option(wire.OPT_PACKET_SHADOW, on)
+        core.set_option(wire.OPT_PACKET_PRIMARY, on)
+        core.set_dirty()
+        core.render_frames(seeds)
+        images.append((core.readback(wire.IMAGE_CONVERGED), core.readback(wire.IMAGE_SHADOWMAP)))
+    H.assert_bits_equal(images[0][0], images[1][0], "converged image, packets on vs off")
+    H.assert_bits_equal(images[0][1], images[1][1], "shadow map, packets on vs off")
+    assert (images[0][1][..., 0] < 1).any()
 
 
 def test_tiles_union_is_bit_identical_to_whole_frame(core):

@@ -17,6 +17,9 @@ frames = int(sys.argv[1]); workload = sys.argv[2]
 sc = scenes.car_standin(1920, 1080) if workload == "car" else scenes.cornell_box(1920, 1080)
 core = native.RtCore(0)
 core.upload(sc); core.bvh_build(); core.set_params(sc.params)
+import os
+for kv in filter(None, os.environ.get("RT_OPTS", "").split(",")):     # e.g. RT_OPTS=0=0,1=0 (rt_set_option pairs)
+    k, v = kv.split("="); core.set_option(int(k), int(v))
 seeds = scenes.frame_seeds(frames, 1)
 core.render_frames(seeds[:2])
 core.reset_stats(); core.enable_kernel_timing(True)
