@@ -119,13 +119,13 @@ int rt_create(int device_id, RtContext **out_ctx)
     memset(&ctx->rootBox, 0, sizeof ctx->rootBox);
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&ctx->dStats, 8 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc((void **)&ctx->dErrorFlag, 4) != hipSuccess || hipMalloc((void **)&ctx->dQCount, 32 * 4) != hipSuccess) {
+        hipMalloc((void **)&ctx->dErrorFlag, 4) != hipSuccess || hipMalloc((void **)&ctx->dQCount, RT_COUNTER_BLOCK_WORDS * 4) != hipSuccess) {
         delete ctx;
         return RT_E_DEVICE;
     }
     (void)hipMemset(ctx->dStats, 0, 8 * sizeof(unsigned long long));
     (void)hipMemset(ctx->dErrorFlag, 0, 4);
-    (void)hipMemset(ctx->dQCount, 0, 32 * 4);
+    (void)hipMemset(ctx->dQCount, 0, RT_COUNTER_BLOCK_WORDS * 4);
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) ctx->numCU = cus;
     *out_ctx = ctx;

@@ -170,9 +170,11 @@ template <int MODE>
 static void launch_scan(RtContext *ctx, const uint32_t *in, uint32_t *out, uint32_t M, uint32_t *blockSums)
 {
     const uint32_t nb = (M + SCAN_TILE - 1) / SCAN_TILE;
+    rt_timer_begin(ctx, MODE == 0 ? "k_scan" : "k_dedup");
     hipLaunchKernelGGL((k_scan_reduce<MODE>), dim3(nb), dim3(SCAN_THREADS), 0, ctx->stream, in, M, blockSums);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, ctx->stream, blockSums, nb);
     hipLaunchKernelGGL((k_scan_apply<MODE>), dim3(nb), dim3(SCAN_THREADS), 0, ctx->stream, in, out, M, blockSums);
+    rt_timer_end(ctx);
 }
 
 // ------------------------------------------------------------------ radix sort
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(256) void k_tree(const uint32_t *__restrict__ codes
 __global__ __launch_bounds__(256) void k_fit(uint32_t N, uint32_t iter, const uint32_t *__restrict__ left,
                                               const uint32_t *__restrict__ right, const uint32_t *__restrict__ sortedIdx,
                                               const float4 *__restrict__ triAABB, float4 *bvhData, uint32_t *done,
-                                              float4 *__restrict__ nodes, uint32_t *__restrict__ remaining)
+                                              float4 *__restrict__ nodes)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N - 1) return;
@@ -354,7 +356,6 @@ __global__ __launch_bounds__(256) void k_fit(uint32_t N, uint32_t iter, const ui
     nodes[i * 4 + 2] = make_float4(rmn.z, rmx.x, rmx.y, rmx.z);
     nodes[i * 4 + 3] = make_float4(__uint_as_float(l), __uint_as_float(r), 0.0f, 0.0f);
     done[i] = iter;
-    atomicSub(remaining, 1u);
 }
 
 // ------------------------------------------------------------------ leaf packing
@@ -457,7 +458,7 @@ int rt_build_impl(RtContext *ctx)
         return RT_OK;
     }
     const uint32_t NI = N - 1;
-    uint32_t *keysB = nullptr, *valsB = nullptr, *blockHist = nullptr, *scanSums = nullptr, *done = nullptr, *remaining = nullptr;
+    uint32_t *keysB = nullptr, *valsB = nullptr, *blockHist = nullptr, *scanSums = nullptr, *done = nullptr;
     const uint32_t nbSort = (N + SORT_TILE - 1) / SORT_TILE;
     const uint32_t histLen = 256u * nbSort;
     const uint32_t nbScanMax = ((histLen > N ? histLen : N) + SCAN_TILE - 1) / SCAN_TILE;
@@ -480,7 +481,6 @@ int rt_build_impl(RtContext *ctx)
     RT_HIP(ctx, dalloc(&blockHist, (size_t)histLen));
     RT_HIP(ctx, dalloc(&scanSums, (size_t)nbScanMax + 1));
     RT_HIP(ctx, dalloc(&done, (size_t)NI));
-    RT_HIP(ctx, dalloc(&remaining, (size_t)1));
 
     hipStream_t st = ctx->stream;
     hipEvent_t e0, e1;
@@ -523,23 +523,22 @@ int rt_build_impl(RtContext *ctx)
                            ctx->dLeafParent);
         rt_timer_end(ctx);
         RT_HIP(ctx, hipMemsetAsync(done, 0xFF, (size_t)NI * 4, st));
-        RT_HIP(ctx, hipMemcpyAsync(remaining, &NI, 4, hipMemcpyHostToDevice, st));
-        uint32_t left = NI;
-        // Tree height <= 32 (strictly growing common prefix of unique 32-bit keys);
-        // check the remaining-node counter every 8 levels to stop early.
-        for (uint32_t iter = 0; iter < 40 && left != 0; ++iter) {
+        uint32_t rootDone = FIT_UNDONE;
+        // Tree height <= 32 (strictly growing common prefix of unique 32-bit keys).  The root is
+        // the last node to complete; look at its word every 8 levels to stop early.
+        for (uint32_t iter = 0; iter < 40 && rootDone == FIT_UNDONE; ++iter) {
             rt_timer_begin(ctx, "k_fit");
             hipLaunchKernelGGL(k_fit, gridNI, blk, 0, st, N, iter, ctx->dLeft, ctx->dRight, ctx->dSortedIdx,
-                               (const float4 *)ctx->dTriAABB, (float4 *)ctx->dBvhData, done, (float4 *)ctx->dNodes, remaining);
+                               (const float4 *)ctx->dTriAABB, (float4 *)ctx->dBvhData, done, (float4 *)ctx->dNodes);
             rt_timer_end(ctx);
             if ((iter & 7u) == 7u) {
-                RT_HIP(ctx, hipMemcpyAsync(&left, remaining, 4, hipMemcpyDeviceToHost, st));
+                RT_HIP(ctx, hipMemcpyAsync(&rootDone, done, 4, hipMemcpyDeviceToHost, st));
                 RT_HIP(ctx, hipStreamSynchronize(st));
             }
         }
-        RT_HIP(ctx, hipMemcpyAsync(&left, remaining, 4, hipMemcpyDeviceToHost, st));
+        RT_HIP(ctx, hipMemcpyAsync(&rootDone, done, 4, hipMemcpyDeviceToHost, st));
         RT_HIP(ctx, hipStreamSynchronize(st));
-        if (left != 0) return rt_fail(ctx, RT_E_STATE, "BVH fit did not converge (%u nodes left)", left);
+        if (rootDone == FIT_UNDONE) return rt_fail(ctx, RT_E_STATE, "BVH fit did not converge");
         RT_HIP(ctx, hipMemcpyAsync(&ctx->rootBox, ctx->dBvhData, sizeof(RtAABB), hipMemcpyDeviceToHost, st));
     } else {
         RT_HIP(ctx, hipMemsetAsync(ctx->dLeafParent, 0xFF, (size_t)N * 4, st));
@@ -562,7 +561,6 @@ int rt_build_impl(RtContext *ctx)
     (void)hipFree(blockHist);
     (void)hipFree(scanSums);
     (void)hipFree(done);
-    (void)hipFree(remaining);
     ctx->built = true;
     return RT_OK;
 }

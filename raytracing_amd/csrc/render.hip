@@ -16,18 +16,43 @@
 
 #include "rt_traverse.h"
 
-// wave64 ballot + prefix-count compaction: appends `slot` of every lane with
-// keep == true to queue[], one atomic per wave.
-__device__ __forceinline__ void queue_push(bool keep, uint32_t slot, uint32_t *__restrict__ queue, uint32_t *__restrict__ count)
+// Queue compaction.  A block works through a tile of Q_TILE entries and leaves in
+// stage[] (LDS) the kept slot or RT_INVALID for every entry, in tile order; the
+// kept ones are appended with ONE global atomic per block (wave64 ballots and
+// prefix counts inside the block).
+// (Atomics on one address are served at ~10 ns each whatever the number of CUs
+// issuing them, so a launch of 16 M threads cannot afford one per wave.)
+#define Q_ITEMS 8
+#define Q_THREADS 256
+#define Q_TILE (Q_ITEMS * Q_THREADS)
+__device__ __forceinline__ void block_queue_flush(const uint32_t *stage, uint32_t *__restrict__ queue, uint32_t *__restrict__ count)
 {
-    const unsigned long long mask = __ballot(keep);
-    if (mask == 0ull) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader, 64);
-    if (keep) queue[base + __popcll(mask & ((1ull << lane) - 1ull))] = slot;
+    __shared__ uint32_t wsum[Q_THREADS / 64];
+    __shared__ uint32_t gbase;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    __syncthreads();
+    uint32_t v[Q_ITEMS], pre[Q_ITEMS], run = 0;
+#pragma unroll
+    for (int it = 0; it < Q_ITEMS; ++it) {
+        v[it] = stage[it * Q_THREADS + tid];
+        const unsigned long long m = __ballot(v[it] != RT_INVALID);
+        pre[it] = run + (uint32_t)__popcll(m & lt);
+        run += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) wsum[wave] = run;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < Q_THREADS / 64; ++w) total += wsum[w];
+        gbase = total ? atomicAdd(count, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = gbase;
+    for (uint32_t w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+    for (int it = 0; it < Q_ITEMS; ++it)
+        if (v[it] != RT_INVALID) queue[base + pre[it]] = v[it];
 }
 
 // ------------------------------------------------------------------ ray sources for traverse_rays
@@ -99,17 +124,17 @@ struct ShadowSrc {
 };
 
 template <bool COUNT, class Src>
-__global__ __launch_bounds__(TRV_THREADS) void k_traverse(RtSceneView sv, Src src, uint32_t *__restrict__ fetchCounter)
+__global__ __launch_bounds__(TRV_THREADS) void k_traverse(RtSceneView sv, Src src, uint32_t *__restrict__ cursor)
 {
     __shared__ uint32_t lds[TRV_LDS_WORDS];
-    traverse_rays<COUNT>(sv, src, fetchCounter, lds);
+    traverse_rays<COUNT>(sv, src, cursor, lds);
 }
 
 template <bool COUNT, class Src>
-__global__ __launch_bounds__(TRV_THREADS) void k_traverse_packets(RtSceneView sv, Src src, uint32_t *__restrict__ fetchCounter)
+__global__ __launch_bounds__(TRV_THREADS) void k_traverse_packets(RtSceneView sv, Src src, uint32_t *__restrict__ cursor)
 {
     __shared__ uint32_t lds[PKT_LDS_WORDS];
-    traverse_packets<COUNT>(sv, src, fetchCounter, lds);
+    traverse_packets<COUNT>(sv, src, cursor, lds);
 }
 
 __global__ void k_unpack_hits(RtSceneView sv, const RtHitRec *__restrict__ hits, uint32_t n, float *t, uint32_t *tri,
@@ -139,32 +164,37 @@ __global__ void k_pack_rays(const float *__restrict__ o3, const float *__restric
 // selects which flag turns the lens camera on (CSMain: the RT_FLAG_DOF_PRIMARY
 // extension; ShadowMap: RT_FLAG_DEPTH_OF_FIELD as in the reference).
 template <uint32_t DOF_FLAG, bool CLEAR_RT>
-__global__ __launch_bounds__(256) void k_generate(RtTileMap tm, RtParams P, const float *__restrict__ seeds, uint32_t nFrames,
-                                                   float4 *__restrict__ po, float4 *__restrict__ pd, float4 *__restrict__ pe,
-                                                   float4 *__restrict__ img, uint2 *__restrict__ rng,
-                                                   uint32_t *__restrict__ queue, uint32_t *__restrict__ qcount)
+__global__ __launch_bounds__(Q_THREADS) void k_generate(RtTileMap tm, RtParams P, const float *__restrict__ seeds, uint32_t nFrames,
+                                                         float4 *__restrict__ po, float4 *__restrict__ pd, float4 *__restrict__ pe,
+                                                         float4 *__restrict__ img, uint2 *__restrict__ rng,
+                                                         uint32_t *__restrict__ queue, uint32_t *__restrict__ qcount)
 {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t stage[Q_TILE];
     const uint32_t total = tm.nSlots * nFrames;
-    const uint32_t frame = g / tm.nSlots, slot = g - frame * tm.nSlots;
-    uint32_t px = 0, py = 0;
-    const bool active = g < total && tm.slot_to_pixel(slot, &px, &py);
-    if (g < total && (CLEAR_RT || !active)) img[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (active) {
-        rt_rng r;
-        rt_rng_init(&r, px, py, seeds[frame]);
-        const float r0 = rt_rand(&r), r1 = rt_rand(&r);
-        const float uvx = (((float)px + r0) - 0.5f) / (float)P.width * 2 - 1;
-        const float uvy = (((float)py + r1) - 0.5f) / (float)P.height * 2 - 1;
-        rt_f3 o, d;
-        if (P.flags & DOF_FLAG) d_dof_camera_ray(P, r, uvx, uvy, o, d);
-        else d_camera_ray(P, uvx, uvy, o, d);
-        po[g] = make_float4(o.x, o.y, o.z, 0.0f);
-        pd[g] = make_float4(d.x, d.y, d.z, 0.0f);
-        if (CLEAR_RT) pe[g] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-        rng[g] = make_uint2(r.state, __float_as_uint(r.seed));
+#pragma unroll 1
+    for (int it = 0; it < Q_ITEMS; ++it) {
+        const uint32_t g = blockIdx.x * Q_TILE + it * Q_THREADS + threadIdx.x;
+        const uint32_t frame = g / tm.nSlots, slot = g - frame * tm.nSlots;
+        uint32_t px = 0, py = 0;
+        const bool active = g < total && tm.slot_to_pixel(slot, &px, &py);
+        if (g < total && (CLEAR_RT || !active)) img[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (active) {
+            rt_rng r;
+            rt_rng_init(&r, px, py, seeds[frame]);
+            const float r0 = rt_rand(&r), r1 = rt_rand(&r);
+            const float uvx = (((float)px + r0) - 0.5f) / (float)P.width * 2 - 1;
+            const float uvy = (((float)py + r1) - 0.5f) / (float)P.height * 2 - 1;
+            rt_f3 o, d;
+            if (P.flags & DOF_FLAG) d_dof_camera_ray(P, r, uvx, uvy, o, d);
+            else d_camera_ray(P, uvx, uvy, o, d);
+            po[g] = make_float4(o.x, o.y, o.z, 0.0f);
+            pd[g] = make_float4(d.x, d.y, d.z, 0.0f);
+            if (CLEAR_RT) pe[g] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            rng[g] = make_uint2(r.state, __float_as_uint(r.seed));
+        }
+        stage[it * Q_THREADS + threadIdx.x] = active ? g : RT_INVALID;
     }
-    queue_push(active, g, queue, qcount);
+    block_queue_flush(stage, queue, qcount);
 }
 
 // Gathers what CheckTriangle copies into RayHit on an accepted hit
@@ -202,15 +232,18 @@ __device__ __forceinline__ void load_hit(const RtSceneView &sv, const RtHitRec &
 // An emissive hit leaves ray and energy untouched in the reference, so the same
 // ray hits the same emitter on every remaining bounce; those identical
 // iterations are added here in one go (same float additions, no re-tracing).
-__global__ __launch_bounds__(256) void k_shade(RtSceneView sv, RtTileMap tm, RtParams P, int bounce, const uint32_t *__restrict__ queueIn,
+__global__ __launch_bounds__(Q_THREADS) void k_shade(RtSceneView sv, RtTileMap tm, RtParams P, int bounce, const uint32_t *__restrict__ queueIn,
                                                 const uint32_t *__restrict__ countIn, uint32_t *__restrict__ queueOut,
                                                 uint32_t *__restrict__ countOut, float4 *__restrict__ po,
                                                 float4 *__restrict__ pd, float4 *__restrict__ pe, float4 *__restrict__ rt,
                                                 uint2 *__restrict__ rng, const RtHitRec *__restrict__ hitRec)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t stage[Q_TILE];
     const uint32_t n = *countIn;
-    if (blockIdx.x * blockDim.x >= n) return;
+    if (blockIdx.x * Q_TILE >= n) return;
+#pragma unroll 1
+    for (int it = 0; it < Q_ITEMS; ++it) {
+    const uint32_t i = blockIdx.x * Q_TILE + it * Q_THREADS + threadIdx.x;
     bool alive = false;
     uint32_t slot = 0;
     if (i < n) {
@@ -265,22 +298,27 @@ __global__ __launch_bounds__(256) void k_shade(RtSceneView sv, RtTileMap tm, RtP
             pe[slot] = make_float4(ray.energy.x, ray.energy.y, ray.energy.z, 0.0f);
         }
     }
-    queue_push(alive, slot, queueOut, countOut);
+    stage[it * Q_THREADS + threadIdx.x] = alive ? slot : RT_INVALID;
+    }
+    block_queue_flush(stage, queueOut, countOut);
 }
 
 // ------------------------------------------------------------------ ShadowMap pass (RayTracing.compute:96-131)
 // generate (primary ray, DoF-capable) -> traverse -> setup (hit point, disk
 // rotation) -> traverse 16 shadow rays per shaded pixel -> resolve.
-__global__ __launch_bounds__(256) void k_sm_setup(RtSceneView sv, RtTileMap tm, RtParams P, const uint32_t *__restrict__ queue,
+__global__ __launch_bounds__(Q_THREADS) void k_sm_setup(RtSceneView sv, RtTileMap tm, RtParams P, const uint32_t *__restrict__ queue,
                                                    const uint32_t *__restrict__ qcount, const float4 *__restrict__ po,
                                                    const float4 *__restrict__ pd, const uint2 *__restrict__ rng,
                                                    const RtHitRec *__restrict__ hitRec, float4 *__restrict__ rec,
                                                    float4 *__restrict__ shadowMap, uint32_t *__restrict__ smq,
                                                    uint32_t *__restrict__ smqCount)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t stage[Q_TILE];
     const uint32_t n = *qcount;
-    if (blockIdx.x * blockDim.x >= n) return;
+    if (blockIdx.x * Q_TILE >= n) return;
+#pragma unroll 1
+    for (int it = 0; it < Q_ITEMS; ++it) {
+    const uint32_t i = blockIdx.x * Q_TILE + it * Q_THREADS + threadIdx.x;
     bool shaded = false;
     uint32_t slot = 0;
     if (i < n) {
@@ -311,7 +349,9 @@ __global__ __launch_bounds__(256) void k_sm_setup(RtSceneView sv, RtTileMap tm, 
             shaded = true;
         }
     }
-    queue_push(shaded, slot, smq, smqCount);
+    stage[it * Q_THREADS + threadIdx.x] = shaded ? slot : RT_INVALID;
+    }
+    block_queue_flush(stage, smq, smqCount);
 }
 
 // SoftShadow's running mean over the 16 rays, in ray order (Shadow.cginc:109-112).
@@ -422,7 +462,7 @@ RtSceneView rt_scene_view(RtContext *ctx)
 
 // Layout of the small counter block (dQCount), zeroed at the start of a batch:
 //   [0..8]  live-path counts of bounce 0..8      [9]  shaded pixels of the ShadowMap pass, [10] its primary rays
-//   [16..23] ray-fetch cursors of the 8 extend launches, [24]/[25] ShadowMap primary / shadow rays, [26] rt_trace_rays
+//   [16..23] ray cursors of the 8 extend launches, [24]/[25] ShadowMap primary / shadow rays, [26] rt_trace_rays
 #define CNT_SMQ 9
 #define CNT_SMPRIM 10
 #define CNT_FETCH 16
@@ -430,6 +470,7 @@ RtSceneView rt_scene_view(RtContext *ctx)
 #define CNT_FETCH_SM1 25
 #define CNT_FETCH_TRACE 26
 #define CNT_WORDS 32
+static_assert(CNT_WORDS <= RT_COUNTER_BLOCK_WORDS, "counter block too small");
 #define RT_MAX_BATCH 8u
 #define RT_MAX_PATH_SLOTS (96u << 20)
 
@@ -508,22 +549,20 @@ uint32_t rt_batch_frames(RtContext *ctx, uint32_t wanted)
 // Persistent launch: enough resident waves to fill the chip; every wave pulls
 // rays from the shared cursor until none are left.
 template <class Src>
-static void launch_traverse(RtContext *ctx, const RtSceneView &sv, const Src &src, uint32_t *fetchCounter, uint32_t maxRays,
-                            const char *name)
+static void launch_traverse(RtContext *ctx, const RtSceneView &sv, const Src &src, uint32_t *cursor, uint32_t maxRays, const char *name)
 {
     uint32_t blocks = (uint32_t)ctx->numCU * 4u;
     const uint32_t need = (maxRays + TRV_THREADS - 1) / TRV_THREADS;
     if (need < blocks) blocks = need ? need : 1;
     rt_timer_begin(ctx, name);
-    if (ctx->countersOn) hipLaunchKernelGGL((k_traverse<true, Src>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, src, fetchCounter);
-    else hipLaunchKernelGGL((k_traverse<false, Src>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, src, fetchCounter);
+    if (ctx->countersOn) hipLaunchKernelGGL((k_traverse<true, Src>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, src, cursor);
+    else hipLaunchKernelGGL((k_traverse<false, Src>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, src, cursor);
     rt_timer_end(ctx);
 }
 
 // Same contract, rays walked 16 at a time (coherent sources only: correct for any rays, fast for coherent ones).
 template <class Src>
-static void launch_traverse_packets(RtContext *ctx, const RtSceneView &sv, const Src &src, uint32_t *fetchCounter, uint32_t maxRays,
-                                    const char *name)
+static void launch_traverse_packets(RtContext *ctx, const RtSceneView &sv, const Src &src, uint32_t *cursor, uint32_t maxRays, const char *name)
 {
     static int perCU[2] = {0, 0};
     const int ci = ctx->countersOn ? 1 : 0;
@@ -538,8 +577,8 @@ static void launch_traverse_packets(RtContext *ctx, const RtSceneView &sv, const
     const uint32_t need = (maxRays + TRV_THREADS - 1) / TRV_THREADS;
     if (need < blocks) blocks = need ? need : 1;
     rt_timer_begin(ctx, name);
-    if (ctx->countersOn) hipLaunchKernelGGL((k_traverse_packets<true, Src>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, src, fetchCounter);
-    else hipLaunchKernelGGL((k_traverse_packets<false, Src>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, src, fetchCounter);
+    if (ctx->countersOn) hipLaunchKernelGGL((k_traverse_packets<true, Src>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, src, cursor);
+    else hipLaunchKernelGGL((k_traverse_packets<false, Src>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, src, cursor);
     rt_timer_end(ctx);
 }
 
@@ -553,7 +592,7 @@ static bool shadow_shares_primary(const RtParams &P)
 static void launch_sm_setup(RtContext *ctx, const RtSceneView &sv, uint32_t total, const uint32_t *queue, const uint32_t *qcount)
 {
     rt_timer_begin(ctx, "k_sm_setup");
-    hipLaunchKernelGGL(k_sm_setup, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, sv, ctx->tile, ctx->params, queue, qcount,
+    hipLaunchKernelGGL(k_sm_setup, dim3((total + Q_TILE - 1) / Q_TILE), dim3(Q_THREADS), 0, ctx->stream, sv, ctx->tile, ctx->params, queue, qcount,
                        ctx->dPo, ctx->dPd, ctx->dRng, ctx->dHit, ctx->dSmRec, ctx->dShadowMap, ctx->dSmQueue, ctx->dQCount + CNT_SMQ);
     rt_timer_end(ctx);
 }
@@ -590,7 +629,7 @@ static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup
     const uint32_t total = n * frames;
     hipStream_t st = ctx->stream;
     const RtSceneView sv = rt_scene_view(ctx);
-    const dim3 blk(256), grid((total + 255) / 256);
+    const dim3 blk(Q_THREADS), grid((total + Q_TILE - 1) / Q_TILE);
     RT_HIP(ctx, hipMemsetAsync(ctx->dQCount, 0, CNT_WORDS * sizeof(uint32_t), st));
     rt_timer_begin(ctx, "k_generate");
     hipLaunchKernelGGL((k_generate<RT_FLAG_DOF_PRIMARY, true>), grid, blk, 0, st, ctx->tile, ctx->params, ctx->dSeeds, frames,
@@ -630,7 +669,7 @@ static int shadowmap_frames(RtContext *ctx, uint32_t frames)
     RT_HIP(ctx, hipMemsetAsync(cnt + CNT_SMQ, 0, 2 * sizeof(uint32_t), st));
     RT_HIP(ctx, hipMemsetAsync(cnt + CNT_FETCH_SM0, 0, 2 * sizeof(uint32_t), st));
     rt_timer_begin(ctx, "k_sm_generate");
-    hipLaunchKernelGGL((k_generate<RT_FLAG_DEPTH_OF_FIELD, false>), dim3((total + 255) / 256), dim3(256), 0, st, ctx->tile, ctx->params,
+    hipLaunchKernelGGL((k_generate<RT_FLAG_DEPTH_OF_FIELD, false>), dim3((total + Q_TILE - 1) / Q_TILE), dim3(Q_THREADS), 0, st, ctx->tile, ctx->params,
                        ctx->dSeeds, frames, ctx->dPo, ctx->dPd, ctx->dPe, ctx->dShadowMap, ctx->dRng, ctx->dQueue[0], cnt + CNT_SMPRIM);
     rt_timer_end(ctx);
     QueueSrc prim;

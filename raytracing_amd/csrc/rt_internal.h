@@ -104,6 +104,8 @@ struct RtPendingEvent {
     hipEvent_t start, stop;
 };
 
+#define RT_COUNTER_BLOCK_WORDS 64   // queue counts (dQCount)
+
 struct RtContext {
     int device = 0;
     hipStream_t stream = nullptr;
