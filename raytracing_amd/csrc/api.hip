@@ -118,12 +118,12 @@ int rt_create(int device_id, RtContext **out_ctx)
     memset(&ctx->tile, 0, sizeof ctx->tile);
     memset(&ctx->rootBox, 0, sizeof ctx->rootBox);
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void **)&ctx->dStats, 8 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void **)&ctx->dStats, 16 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&ctx->dErrorFlag, 4) != hipSuccess || hipMalloc((void **)&ctx->dQCount, RT_COUNTER_BLOCK_WORDS * 4) != hipSuccess) {
         delete ctx;
         return RT_E_DEVICE;
     }
-    (void)hipMemset(ctx->dStats, 0, 8 * sizeof(unsigned long long));
+    (void)hipMemset(ctx->dStats, 0, 16 * sizeof(unsigned long long));
     (void)hipMemset(ctx->dErrorFlag, 0, 4);
     (void)hipMemset(ctx->dQCount, 0, RT_COUNTER_BLOCK_WORDS * 4);
     int cus = 0;
@@ -520,7 +520,7 @@ int rt_reset_stats(RtContext *ctx)
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     rt_timer_resolve(ctx);
     ctx->timers.clear();
-    RT_HIP(ctx, hipMemset(ctx->dStats, 0, 8 * sizeof(unsigned long long)));
+    RT_HIP(ctx, hipMemset(ctx->dStats, 0, 16 * sizeof(unsigned long long)));
     return RT_OK;
 }
 
@@ -529,14 +529,19 @@ int rt_get_stats(RtContext *ctx, RtStats *out)
     RT_ENTER(ctx);
     if (!out) return rt_fail(ctx, RT_E_INVALID, "null stats");
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned long long h[8];
+    unsigned long long h[16];   // [0..7] all launches but the shadow rays, [8..15] shadow-ray launches
     RT_HIP(ctx, hipMemcpy(h, ctx->dStats, sizeof h, hipMemcpyDeviceToHost));
-    out->rays = h[0];
-    out->internalVisits = h[1];
-    out->leafVisits = h[2];
-    out->triTests = h[3];
-    out->hits = h[4];
+    out->rays = h[0] + h[8];
+    out->internalVisits = h[1] + h[9];
+    out->leafVisits = h[2] + h[10];
+    out->triTests = h[3] + h[11];
+    out->hits = h[4] + h[12];
     out->paths = h[5];
+    out->shadowRays = h[8];
+    out->shadowInternalVisits = h[9];
+    out->shadowLeafVisits = h[10];
+    out->shadowTriTests = h[11];
+    out->shadowHits = h[12];
     out->buildMs = ctx->buildMs;
     out->renderMs = ctx->renderMs;
     return RT_OK;

@@ -598,8 +598,10 @@ static void launch_sm_setup(RtContext *ctx, const RtSceneView &sv, uint32_t tota
 }
 
 // 16 shadow rays per shaded pixel + the running mean (needs dSmQueue / dSmRec filled by k_sm_setup).
-static void launch_shadow_rays(RtContext *ctx, const RtSceneView &sv, uint32_t total)
+static void launch_shadow_rays(RtContext *ctx, const RtSceneView &sceneView, uint32_t total)
 {
+    RtSceneView sv = sceneView;
+    sv.stats = ctx->dStats + 8;                  // counted apart from the other traversals
     const RtParams &P = ctx->params;
     ShadowSrc sh;
     sh.smq = ctx->dSmQueue;

@@ -162,7 +162,7 @@ struct RtContext {
     uint32_t sampleCount = 0;
 
     // stats / timing
-    unsigned long long *dStats = nullptr; // 8 x u64
+    unsigned long long *dStats = nullptr; // 2 banks of 8 x u64
     uint32_t *dErrorFlag = nullptr;
     bool countersOn = false;
     bool timingOn = false;

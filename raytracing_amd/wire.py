@@ -71,7 +71,9 @@ class RtParams(C.Structure):
 class RtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("internalVisits", C.c_uint64), ("leafVisits", C.c_uint64),
                 ("triTests", C.c_uint64), ("hits", C.c_uint64), ("paths", C.c_uint64),
-                ("buildMs", C.c_double), ("renderMs", C.c_double)]
+                ("buildMs", C.c_double), ("renderMs", C.c_double),
+                ("shadowRays", C.c_uint64), ("shadowInternalVisits", C.c_uint64), ("shadowLeafVisits", C.c_uint64),
+                ("shadowTriTests", C.c_uint64), ("shadowHits", C.c_uint64)]
 
 # rt_set_option
 OPT_PACKET_SHADOW, OPT_PACKET_PRIMARY, OPT_PACKET_TRACE, OPT_BATCH_FRAMES = 0, 1, 2, 3
