@@ -83,7 +83,9 @@ class Oracle:
         out["morton_unsorted"], out["morton_sorted_raw"] = un, raw
         return out
 
-    def trace(self, origins, directions, brute=False):
+    def trace(self, origins, directions, brute=False, grid=False):
+        """First hits.  brute: loop over all triangles.  grid: the library's grid walk
+        (same hits as the reference's walk, its own box-test counts)."""
         o = np.ascontiguousarray(origins, np.float32)
         d = np.ascontiguousarray(directions, np.float32)
         n = len(o)
@@ -92,9 +94,17 @@ class Oracle:
             lib().orc_trace_brute(self.h, _p(o), _p(d), C.c_uint32(n), _p(t), _p(tri))
             return dict(t=t, triangle=tri)
         u, v, cnt = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(5, np.uint64)
-        lib().orc_trace(self.h, _p(o), _p(d), C.c_uint32(n), _p(t), _p(tri), _p(u), _p(v), _p(cnt))
+        fn = lib().orc_trace_grid if grid else lib().orc_trace
+        fn(self.h, _p(o), _p(d), C.c_uint32(n), _p(t), _p(tri), _p(u), _p(v), _p(cnt))
         return dict(t=t, triangle=tri, u=u, v=v,
                     counters=dict(zip(("rays", "internalVisits", "leafVisits", "triTests", "hits"), map(int, cnt))))
+
+    def grid(self):
+        """(ok, grid[6] = org xyz + step xyz, qboxes[n_internal, 6]) of the 16-bit traversal grid."""
+        g = np.zeros(6, np.float32)
+        q = np.zeros((max(self.n - 1, 0), 6), np.uint32)
+        ok = lib().orc_grid(self.h, _p(g), _p(q))
+        return bool(ok), g, q
 
     def render(self, params, counters=False):
         img = np.zeros((params.height, params.width, 4), np.float32)

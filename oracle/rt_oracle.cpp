@@ -20,6 +20,7 @@
 
 #include "../include/rtcore.h"
 #include "../include/rt_math.h"
+#include "../include/rt_q16.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -78,6 +79,11 @@ struct Scene {
     std::vector<RtLeafNode> leaves;
     std::vector<RtAABB> bvhData;
     bool built = false;
+
+    // the library's 16-bit traversal grid (include/rt_q16.h), rebuilt here from the oracle's own tree
+    RtQGrid grid;
+    std::vector<uint32_t> qboxes;      // 6 words per internal node: left box, right box
+    bool gridOk = true;
 };
 
 // Per-thread "globals" of the shader (Header.cginc:61-64) + uniforms.
@@ -328,6 +334,35 @@ void BVHConstructor(Scene &s)
     }
 }
 
+// The library's traversal boxes: every child box of the tree rounded outward onto
+// the 16-bit grid of the root box (include/rt_q16.h), 3 words per box.
+void BuildGridBoxes(Scene &s)
+{
+    s.qboxes.clear();
+    s.gridOk = true;
+    if (s.N < 2) return;
+    s.grid = rt_q16_grid(s.bvhData[0].min, s.bvhData[0].max);
+    s.qboxes.resize((size_t)(s.N - 1) * 6);
+    for (uint32_t i = 0; i + 1 < s.N; ++i) {
+        const RtInternalNode &n = s.inodes[i];
+        const uint32_t child[2] = {n.leftNode, n.rightNode}, type[2] = {n.leftNodeType, n.rightNodeType};
+        for (int c = 0; c < 2; ++c) {
+            const RtAABB &b = type[c] == RT_INTERNAL_NODE ? s.bvhData[child[c]] : s.triAABB[s.sortedIdx[s.leaves[child[c]].index]];
+            uint32_t lo[3], hi[3];
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = rt_q16_floor(s.grid.org[a], s.grid.step[a], b.min[a]);
+                hi[a] = rt_q16_ceil(s.grid.org[a], s.grid.step[a], b.max[a]);
+                if (rt_q16_plane(s.grid.org[a], s.grid.step[a], lo[a]) > b.min[a] || hi[a] > RT_Q16_MAX) s.gridOk = false;
+                if (hi[a] > RT_Q16_MAX) hi[a] = RT_Q16_MAX;
+            }
+            uint32_t *w = &s.qboxes[(size_t)i * 6 + c * 3];
+            w[0] = lo[0] | (lo[1] << 16);
+            w[1] = lo[2] | (hi[0] << 16);
+            w[2] = hi[1] | (hi[2] << 16);
+        }
+    }
+}
+
 void Build(Scene &s)
 {
     Calculate(s);
@@ -338,6 +373,7 @@ void Build(Scene &s)
     s.morton = keys;
     TreeConstructor(s);
     BVHConstructor(s);
+    BuildGridBoxes(s);
     s.built = true;
 }
 
@@ -454,6 +490,52 @@ void IntersectTriangle(const Scene &s, const Ray &ray, RayHit &hit, TraceCounter
             CheckTriangle(s, triangleIndex, ray, hit, cnt);
         }
         if (currentStackIndex > 64) { fprintf(stderr, "oracle: traversal stack overflow\n"); abort(); }
+    }
+}
+
+// ------------------------------------------------------------------ grid walk (no reference counterpart)
+// Restates the library's one-ray-per-lane walker on the CPU so that its work
+// counters can be compared exactly and its claim "same hit as the reference's
+// walk" can be checked on the CPU as well: child boxes rounded outward onto the
+// 16-bit grid of the root box and tested with rt_slab_maybe; the triangle's own
+// box exact, with the reference's test; rays with a zero / non-finite component
+// use the exact boxes and the reference's test everywhere.
+const RtAABB &ChildBox(const Scene &s, uint32_t node, uint32_t type)
+{
+    return type == RT_INTERNAL_NODE ? s.bvhData[node] : s.triAABB[s.sortedIdx[s.leaves[node].index]];
+}
+
+void IntersectTriangleGrid(const Scene &s, const Ray &ray, RayHit &hit, TraceCounters *cnt)
+{
+    if (s.N == 0) return;
+    if (cnt) cnt->internalVisits++;
+    if (s.N < 2 || !RayBoxIntersection(s.bvhData[0], ray)) return;
+    const bool odd = rt_ray_needs_exact_walk(ray.origin, ray.direction);
+    const f3 r = rt_mk3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
+    const RtRaySlab slab = rt_ray_slab(s.grid, ray.origin, r);
+    uint32_t stack[64];
+    uint32_t sp = 0;
+    stack[sp++] = 0;
+    while (sp != 0) {
+        const uint32_t index = stack[--sp];
+        const RtInternalNode &n = s.inodes[index];
+        if (cnt) cnt->internalVisits += 2;
+        bool pass[2];
+        const uint32_t child[2] = {n.leftNode, n.rightNode}, type[2] = {n.leftNodeType, n.rightNodeType};
+        for (int c = 0; c < 2; ++c) {
+            if (odd) {
+                pass[c] = RayBoxIntersection(ChildBox(s, child[c], type[c]), ray);
+            } else {
+                const uint32_t *w = &s.qboxes[(size_t)index * 6 + c * 3];
+                pass[c] = rt_slab_maybe(slab, w[0], w[1], w[2]);
+            }
+        }
+        // left leaf, right leaf, then the right subtree before the left one
+        for (int c = 0; c < 2; ++c)
+            if (type[c] != RT_INTERNAL_NODE && pass[c]) CheckTriangle(s, s.sortedIdx[s.leaves[child[c]].index], ray, hit, cnt);
+        for (int c = 0; c < 2; ++c)
+            if (type[c] == RT_INTERNAL_NODE && pass[c]) stack[sp++] = child[c];
+        if (sp > 62) { fprintf(stderr, "oracle: traversal stack overflow\n"); abort(); }
     }
 }
 
@@ -1195,6 +1277,50 @@ void orc_trace(void *h, const float *o, const float *d, uint32_t n, float *out_t
         counters[0] = total.rays; counters[1] = total.internalVisits; counters[2] = total.leafVisits;
         counters[3] = total.triTests; counters[4] = total.hits;
     }
+}
+
+// The same queries through the grid walk (IntersectTriangleGrid).
+void orc_trace_grid(void *h, const float *o, const float *d, uint32_t n, float *out_t, uint32_t *out_tri,
+                    float *out_u, float *out_v, uint64_t *counters)
+{
+    const Scene &s = *(Scene *)h;
+    TraceCounters total = {0, 0, 0, 0, 0};
+#pragma omp parallel
+    {
+        TraceCounters c = {0, 0, 0, 0, 0};
+#pragma omp for schedule(dynamic, 256)
+        for (long long i = 0; i < (long long)n; ++i) {
+            Ray r = CreateRay(ld3(o + 3 * i), ld3(d + 3 * i));
+            RayHit hit = CreateRayHit();
+            c.rays++;
+            IntersectTriangleGrid(s, r, hit, &c);
+            if (hit.distance < rt_inf()) c.hits++;
+            if (out_t) out_t[i] = hit.distance;
+            if (out_tri) out_tri[i] = hit.triangle;
+            if (out_u) out_u[i] = hit.u;
+            if (out_v) out_v[i] = hit.v;
+        }
+#pragma omp critical
+        {
+            total.rays += c.rays; total.internalVisits += c.internalVisits; total.leafVisits += c.leafVisits;
+            total.triTests += c.triTests; total.hits += c.hits;
+        }
+    }
+    if (counters) {
+        counters[0] = total.rays; counters[1] = total.internalVisits; counters[2] = total.leafVisits;
+        counters[3] = total.triTests; counters[4] = total.hits;
+    }
+}
+
+// 1 when every box fitted the grid; grid6 = org[3], step[3]; qboxes = 6 words per internal node (may be NULL).
+int orc_grid(void *h, float *grid6, uint32_t *qboxes)
+{
+    const Scene &s = *(Scene *)h;
+    if (s.N >= 2) {
+        if (grid6) { memcpy(grid6, s.grid.org, 12); memcpy(grid6 + 3, s.grid.step, 12); }
+        if (qboxes) memcpy(qboxes, s.qboxes.data(), s.qboxes.size() * 4);
+    }
+    return s.gridOk ? 1 : 0;
 }
 
 // Brute force over every triangle in original order, no boxes: the closest

@@ -95,6 +95,7 @@ static int check_error_flag(RtContext *ctx)
     RT_HIP(ctx, hipMemcpy(&flag, ctx->dErrorFlag, 4, hipMemcpyDeviceToHost));
     if (flag) {
         (void)hipMemset(ctx->dErrorFlag, 0, 4);
+        if (flag == 2u) return rt_fail(ctx, RT_E_STATE, "BVH build: a box does not fit the 16-bit grid of the root box");
         return rt_fail(ctx, RT_E_OVERFLOW, "traversal stack overflow (depth > %d)", RT_STACK_DEPTH);
     }
     return RT_OK;
@@ -117,17 +118,18 @@ int rt_create(int device_id, RtContext **out_ctx)
     memset(&ctx->params, 0, sizeof ctx->params);
     memset(&ctx->tile, 0, sizeof ctx->tile);
     memset(&ctx->rootBox, 0, sizeof ctx->rootBox);
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) ctx->numCU = cus;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&ctx->dStats, 16 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMalloc((void **)&ctx->dErrorFlag, 4) != hipSuccess || hipMalloc((void **)&ctx->dQCount, RT_COUNTER_BLOCK_WORDS * 4) != hipSuccess) {
+        hipMalloc((void **)&ctx->dErrorFlag, 4) != hipSuccess || hipMalloc((void **)&ctx->dQCount, RT_COUNTER_BLOCK_WORDS * 4) != hipSuccess ||
+        hipMalloc((void **)&ctx->dStackSpill, (size_t)ctx->numCU * RT_SPILL_WORDS_PER_CU * 4) != hipSuccess) {
         delete ctx;
         return RT_E_DEVICE;
     }
     (void)hipMemset(ctx->dStats, 0, 16 * sizeof(unsigned long long));
     (void)hipMemset(ctx->dErrorFlag, 0, 4);
     (void)hipMemset(ctx->dQCount, 0, RT_COUNTER_BLOCK_WORDS * 4);
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) ctx->numCU = cus;
     *out_ctx = ctx;
     return RT_OK;
 }
@@ -142,7 +144,7 @@ int rt_destroy(RtContext *ctx)
     rt_free_build(ctx);
     rt_free_render(ctx);
     void *ptrs[] = {ctx->dVerts, ctx->dIdx, ctx->dMatIdx, ctx->dShadow, ctx->dMats, ctx->dSphere, ctx->dArea,
-                    ctx->dDisc, ctx->dCube, ctx->dStats, ctx->dErrorFlag, ctx->dQCount};
+                    ctx->dDisc, ctx->dCube, ctx->dStats, ctx->dErrorFlag, ctx->dQCount, ctx->dStackSpill};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -220,7 +222,7 @@ int rt_bvh_build(RtContext *ctx)
     if (ctx->N && !ctx->dVerts) return rt_fail(ctx, RT_E_STATE, "rt_bvh_build before rt_scene_upload");
     const int rc = rt_build_impl(ctx);
     rt_timer_resolve(ctx);
-    return rc;
+    return rc ? rc : check_error_flag(ctx);
 }
 
 int rt_readback_bvh(RtContext *ctx, uint32_t *morton_codes, uint32_t *sorted_triangle_index, RtAABB *triangle_aabb,

@@ -358,23 +358,59 @@ __global__ __launch_bounds__(256) void k_fit(uint32_t N, uint32_t iter, const ui
     done[i] = iter;
 }
 
+// ------------------------------------------------------------------ 16-bit traversal nodes
+// Rounds every child box of the finished tree outward onto the root-box grid
+// (rt_q16.h).  A plane the grid cannot cover raises the error flag.
+__device__ inline bool quantise_box(const RtQGrid &g, const float mn[3], const float mx[3], uint32_t out[3])
+{
+    uint32_t lo[3], hi[3];
+    bool ok = true;
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = rt_q16_floor(g.org[a], g.step[a], mn[a]);
+        hi[a] = rt_q16_ceil(g.org[a], g.step[a], mx[a]);
+        ok = ok && rt_q16_plane(g.org[a], g.step[a], lo[a]) <= mn[a] && hi[a] <= RT_Q16_MAX;
+        if (hi[a] > RT_Q16_MAX) hi[a] = RT_Q16_MAX;
+    }
+    out[0] = lo[0] | (lo[1] << 16);
+    out[1] = lo[2] | (hi[0] << 16);
+    out[2] = hi[1] | (hi[2] << 16);
+    return ok;
+}
+
+__global__ __launch_bounds__(256) void k_quantise(uint32_t NI, RtQGrid g, const RtNode64 *__restrict__ nodes,
+                                                   uint4 *__restrict__ qnodes, uint32_t *__restrict__ errorFlag)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NI) return;
+    const RtNode64 n = nodes[i];
+    uint32_t l[3], r[3];
+    const bool okL = quantise_box(g, n.lmin, n.lmax, l);
+    const bool okR = quantise_box(g, n.rmin, n.rmax, r);
+    if (!okL || !okR) *errorFlag = 2u;
+    qnodes[i * 2 + 0] = make_uint4(l[0], l[1], l[2], r[0]);
+    qnodes[i * 2 + 1] = make_uint4(r[1], r[2], n.left, n.right);
+}
+
 // ------------------------------------------------------------------ leaf packing
 __global__ __launch_bounds__(256) void k_pack_leaves(uint32_t N, const uint32_t *__restrict__ sortedIdx,
                                                       const uint32_t *__restrict__ idx, const float *__restrict__ verts,
                                                       const uint32_t *__restrict__ matIdx, const int32_t *__restrict__ shadow,
-                                                      float4 *__restrict__ leafTri, float4 *__restrict__ leafShade)
+                                                      const float4 *__restrict__ triAABB, float4 *__restrict__ leafTri,
+                                                      float4 *__restrict__ leafShade)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= N) return;
     const uint32_t t = sortedIdx[j];
+    const float4 bmn = triAABB[t * 2], bmx = triAABB[t * 2 + 1];
     const uint32_t i0 = idx[t * 3 + 0], i1 = idx[t * 3 + 1], i2 = idx[t * 3 + 2];
     const float *a = verts + (size_t)i0 * 11, *b = verts + (size_t)i1 * 11, *c = verts + (size_t)i2 * 11;
     const rt_f3 v0 = rt_mk3(a[0], a[1], a[2]);
     const rt_f3 e1 = rt_sub3(rt_mk3(b[0], b[1], b[2]), v0);
     const rt_f3 e2 = rt_sub3(rt_mk3(c[0], c[1], c[2]), v0);
-    leafTri[j * 3 + 0] = make_float4(v0.x, v0.y, v0.z, e1.x);
-    leafTri[j * 3 + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
-    leafTri[j * 3 + 2] = make_float4(e2.z, __uint_as_float(t), 0.0f, 0.0f);
+    leafTri[j * 4 + 0] = make_float4(v0.x, v0.y, v0.z, e1.x);
+    leafTri[j * 4 + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+    leafTri[j * 4 + 2] = make_float4(e2.z, __uint_as_float(t), bmn.x, bmn.y);
+    leafTri[j * 4 + 3] = make_float4(bmn.z, bmx.x, bmx.y, bmx.z);
     leafShade[j * 3 + 0] = make_float4(a[3], a[4], a[5], b[3]);
     leafShade[j * 3 + 1] = make_float4(b[4], b[5], c[3], c[4]);
     leafShade[j * 3 + 2] = make_float4(c[5], __uint_as_float(matIdx[t]), __int_as_float(shadow[t * 2 + 0]), 0.0f);
@@ -433,7 +469,7 @@ void rt_free_build(RtContext *ctx)
 {
     void **ptrs[] = {(void **)&ctx->dTriAABB, (void **)&ctx->dMortonUnsorted, (void **)&ctx->dMortonSortedRaw,
                      (void **)&ctx->dMorton, (void **)&ctx->dSortedIdx, (void **)&ctx->dLeft, (void **)&ctx->dRight,
-                     (void **)&ctx->dParent, (void **)&ctx->dLeafParent, (void **)&ctx->dBvhData, (void **)&ctx->dNodes,
+                     (void **)&ctx->dParent, (void **)&ctx->dLeafParent, (void **)&ctx->dBvhData, (void **)&ctx->dNodes, (void **)&ctx->dQNodes,
                      (void **)&ctx->dLeafTri, (void **)&ctx->dLeafShade};
     for (void **p : ptrs) {
         if (*p) (void)hipFree(*p);
@@ -474,6 +510,7 @@ int rt_build_impl(RtContext *ctx)
     RT_HIP(ctx, dalloc(&ctx->dLeafParent, (size_t)N));
     RT_HIP(ctx, dalloc(&ctx->dBvhData, (size_t)NI));
     RT_HIP(ctx, dalloc(&ctx->dNodes, (size_t)NI));
+    RT_HIP(ctx, dalloc(&ctx->dQNodes, (size_t)NI));
     RT_HIP(ctx, dalloc(&ctx->dLeafTri, (size_t)N));
     RT_HIP(ctx, dalloc(&ctx->dLeafShade, (size_t)N));
     RT_HIP(ctx, dalloc(&keysB, (size_t)N));
@@ -540,12 +577,18 @@ int rt_build_impl(RtContext *ctx)
         RT_HIP(ctx, hipStreamSynchronize(st));
         if (rootDone == FIT_UNDONE) return rt_fail(ctx, RT_E_STATE, "BVH fit did not converge");
         RT_HIP(ctx, hipMemcpyAsync(&ctx->rootBox, ctx->dBvhData, sizeof(RtAABB), hipMemcpyDeviceToHost, st));
+        RT_HIP(ctx, hipStreamSynchronize(st));
+        ctx->grid = rt_q16_grid(ctx->rootBox.min, ctx->rootBox.max);
+        rt_timer_begin(ctx, "k_quantise");
+        hipLaunchKernelGGL(k_quantise, gridNI, blk, 0, st, NI, ctx->grid, ctx->dNodes, (uint4 *)ctx->dQNodes, ctx->dErrorFlag);
+        rt_timer_end(ctx);
     } else {
         RT_HIP(ctx, hipMemsetAsync(ctx->dLeafParent, 0xFF, (size_t)N * 4, st));
     }
     rt_timer_begin(ctx, "k_pack_leaves");
     hipLaunchKernelGGL(k_pack_leaves, gridN, blk, 0, st, N, ctx->dSortedIdx, ctx->dIdx, (const float *)ctx->dVerts,
-                       ctx->dMatIdx, ctx->dShadow, (float4 *)ctx->dLeafTri, (float4 *)ctx->dLeafShade);
+                       ctx->dMatIdx, ctx->dShadow, (const float4 *)ctx->dTriAABB, (float4 *)ctx->dLeafTri,
+                       (float4 *)ctx->dLeafShade);
     rt_timer_end(ctx);
 
     RT_HIP(ctx, hipEventRecord(e1, st));

@@ -443,6 +443,8 @@ RtSceneView rt_scene_view(RtContext *ctx)
     RtSceneView sv;
     memset(&sv, 0, sizeof sv);
     sv.nodes = ctx->dNodes;
+    sv.qnodes = ctx->dQNodes;
+    sv.grid = ctx->grid;
     sv.leafTri = ctx->dLeafTri;
     sv.leafShade = ctx->dLeafShade;
     sv.materials = ctx->dMats;
@@ -456,6 +458,7 @@ RtSceneView rt_scene_view(RtContext *ctx)
     sv.cube = ctx->dCube;
     sv.cubeSize = ctx->cubeSize;
     sv.stats = ctx->dStats;
+    sv.stackSpill = ctx->dStackSpill;
     sv.errorFlag = ctx->dErrorFlag;
     return sv;
 }
@@ -551,7 +554,15 @@ uint32_t rt_batch_frames(RtContext *ctx, uint32_t wanted)
 template <class Src>
 static void launch_traverse(RtContext *ctx, const RtSceneView &sv, const Src &src, uint32_t *cursor, uint32_t maxRays, const char *name)
 {
-    uint32_t blocks = (uint32_t)ctx->numCU * 4u;
+    static int perCU[2] = {0, 0};
+    const int ci = ctx->countersOn ? 1 : 0;
+    if (perCU[ci] == 0) {
+        int n = 0;
+        hipError_t e = ctx->countersOn ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse<true, Src>, TRV_THREADS, 0)
+                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse<false, Src>, TRV_THREADS, 0);
+        perCU[ci] = (e == hipSuccess && n > 0) ? (n < TRV_MAX_BLOCKS_PER_CU ? n : TRV_MAX_BLOCKS_PER_CU) : 4;
+    }
+    uint32_t blocks = (uint32_t)ctx->numCU * (uint32_t)perCU[ci];
     const uint32_t need = (maxRays + TRV_THREADS - 1) / TRV_THREADS;
     if (need < blocks) blocks = need ? need : 1;
     rt_timer_begin(ctx, name);

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/rt_math.h"
+#include "../../include/rt_q16.h"
 #include "../../include/rtcore.h"
 
 #define RT_LEAF_BIT 0x80000000u
@@ -29,14 +30,24 @@ struct __attribute__((aligned(16))) RtNode64 {
 };
 static_assert(sizeof(RtNode64) == 64, "node layout");
 
-// Intersection record of the triangle at sorted leaf j: v0 and the two edge
-// vectors (the same subtractions IntersectTriangle_MT97 performs first).
+// The node the one-ray-per-lane walker reads, 32 B: both children's boxes on the
+// 16-bit grid of rt_q16.h (each CONTAINS the exact box of RtNode64).
+// box words: lo.x | lo.y << 16,  lo.z | hi.x << 16,  hi.y | hi.z << 16
+struct __attribute__((aligned(16))) RtQNode {
+    uint32_t lbox[3], rbox0;
+    uint32_t rbox1, rbox2, left, right;   // index | RT_LEAF_BIT
+};
+static_assert(sizeof(RtQNode) == 32, "quantised node layout");
+
+// Intersection record of the triangle at sorted leaf j, 64 B: v0 and the two
+// edge vectors (the same subtractions IntersectTriangle_MT97 performs first)
+// and the triangle's exact padded box (triangleAABB[tri]).
 struct __attribute__((aligned(16))) RtLeafTri {
     float v0[3], e1[3], e2[3];
     uint32_t tri;              // original triangle index
-    uint32_t pad0, pad1;
+    float bmin[3], bmax[3];
 };
-static_assert(sizeof(RtLeafTri) == 48, "leaf layout");
+static_assert(sizeof(RtLeafTri) == 64, "leaf layout");
 
 // Shading record of the triangle at sorted leaf j.
 struct __attribute__((aligned(16))) RtLeafShade {
@@ -55,6 +66,8 @@ struct RtHitRec {              // 16 B: result of one BVHRayTrace
 // Pointers a traversal / shading kernel needs, passed by value.
 struct RtSceneView {
     const RtNode64 *nodes;
+    const RtQNode *qnodes;
+    RtQGrid grid;
     const RtLeafTri *leafTri;
     const RtLeafShade *leafShade;
     const RtMaterialData *materials;
@@ -66,6 +79,7 @@ struct RtSceneView {
     uint32_t nSphere, nArea;
     const float4 *cube;
     uint32_t cubeSize;
+    uint32_t *stackSpill;      // deep stack levels of the one-ray-per-lane walker
     unsigned long long *stats; // 8 counters or nullptr
     uint32_t *errorFlag;
 };
@@ -105,6 +119,7 @@ struct RtPendingEvent {
 };
 
 #define RT_COUNTER_BLOCK_WORDS 64   // queue counts (dQCount)
+#define RT_SPILL_WORDS_PER_CU (8 * 256 * RT_STACK_DEPTH)   // room for every stack level of 8 blocks of 256 lanes
 
 struct RtContext {
     int device = 0;
@@ -134,6 +149,8 @@ struct RtContext {
     uint32_t *dLeft = nullptr, *dRight = nullptr, *dParent = nullptr, *dLeafParent = nullptr;
     RtAABB *dBvhData = nullptr;
     RtNode64 *dNodes = nullptr;
+    RtQNode *dQNodes = nullptr;
+    RtQGrid grid;
     RtLeafTri *dLeafTri = nullptr;
     RtLeafShade *dLeafShade = nullptr;
     RtAABB rootBox;
@@ -162,6 +179,7 @@ struct RtContext {
     uint32_t sampleCount = 0;
 
     // stats / timing
+    uint32_t *dStackSpill = nullptr;     // numCU * 8 blocks * 256 lanes * (RT_STACK_DEPTH - TRV_STACK_LDS) words
     unsigned long long *dStats = nullptr; // 2 banks of 8 x u64
     uint32_t *dErrorFlag = nullptr;
     bool countersOn = false;

@@ -8,12 +8,23 @@
 // on equal distances the triangle met first in the reference's depth-first
 // order (left leaf, right leaf, right subtree, left subtree) is kept.
 //
-// What is different is only HOW the same decisions are computed:
-//   * one 64-byte node fetch brings both children's boxes;
-//   * the slab test is first evaluated with per-ray reciprocals and an error
-//     margin; only when the margin cannot decide (a graze within a few ulp, an
-//     infinity, a NaN) are the reference's six true divisions evaluated, so the
-//     boolean is always the one the reference computes;
+// What is different is only HOW the same result is computed:
+//   * Inner nodes are a filter, not a decision.  With finite, non-zero direction
+//     components IEEE subtraction and division are monotone, so a ray that passes
+//     a triangle's own box passes every box that contains it: the set of triangles
+//     the reference ends up testing is exactly "own box passes", and the order it
+//     meets them in is fixed by the tree.  Any walk of the same tree, in the same
+//     child order, that never skips a subtree holding such a triangle returns the
+//     same hit, bit for bit.  The one-ray-per-lane walker therefore reads 32-byte
+//     nodes whose child boxes are rounded OUTWARD onto a 16-bit grid (rt_q16.h)
+//     and tests them with a cheap test that may say "maybe" but never a wrong
+//     "no"; the triangle's own box is exact and gets the reference's test.
+//     Rays outside the monotone case (a zero / infinite / NaN component) walk the
+//     exact 64-byte nodes with the reference's test at every node instead.
+//   * the reference's slab test is first evaluated with per-ray reciprocals and an
+//     error margin; only when the margin cannot decide (a graze within a few ulp,
+//     an infinity, a NaN) are the six true divisions evaluated, so the boolean is
+//     always the one the reference computes;
 //   * a wave keeps fetching new rays for lanes whose ray has finished
 //     (ballot + prefix count + one atomic per refill), and triangle tests are
 //     queued per lane in LDS and run in batches, in per-ray order, so that the
@@ -24,12 +35,18 @@
 #include "rt_internal.h"
 
 #define TRV_THREADS 256
-#define TRV_PEND_CAP 8          // queued triangle tests per lane
+#ifndef TRV_PEND_CAP
+#define TRV_PEND_CAP 4          // queued triangle tests per lane
+#endif
+#ifndef TRV_STACK_LDS
+#define TRV_STACK_LDS 16        // stack levels kept in LDS; deeper levels spill to HBM (rare)
+#endif
+#define TRV_MAX_BLOCKS_PER_CU 8
 #define TRV_NODE_BURST 48       // node steps between two triangle batches
 #define TRV_REFILL_MIN 24       // refill when at least this many lanes are idle
 #define TRV_EARLY_OUT 40        // leave a burst when this many lanes have nothing to walk
 #define TRV_DONE 0xFFFFFFFFu
-#define TRV_LDS_WORDS ((RT_STACK_DEPTH + TRV_PEND_CAP) * TRV_THREADS)
+#define TRV_LDS_WORDS ((TRV_STACK_LDS + TRV_PEND_CAP) * TRV_THREADS)
 
 // The reference's slab test, verbatim: true divisions, min/max that return the
 // non-NaN operand (v_min_f32 / v_max_f32 in IEEE mode).
@@ -70,13 +87,10 @@ __device__ __forceinline__ bool box_hit(float bminx, float bminy, float bminz, f
     return box_hit_exact(bminx, bminy, bminz, bmaxx, bmaxy, bmaxz, o, d);
 }
 
-// IntersectTriangle_MT97 + the acceptance test of CheckTriangle, on the stored
-// (v0, e1 = v1 - v0, e2 = v2 - v0) record of sorted leaf `leaf`.
-__device__ __forceinline__ void tri_test(const RtSceneView &sv, uint32_t leaf, const rt_f3 o, const rt_f3 d, RtHitRec &h)
+// IntersectTriangle_MT97 + the acceptance test of CheckTriangle.
+__device__ __forceinline__ void tri_test_values(const rt_f3 v0, const rt_f3 e1, const rt_f3 e2, uint32_t leaf, const rt_f3 o,
+                                                const rt_f3 d, RtHitRec &h)
 {
-    const float4 *p = (const float4 *)(sv.leafTri + leaf);
-    const float4 a = p[0], b = p[1], c = p[2];
-    const rt_f3 v0 = rt_mk3(a.x, a.y, a.z), e1 = rt_mk3(a.w, b.x, b.y), e2 = rt_mk3(b.z, b.w, c.x);
     const rt_f3 pvec = rt_cross3(d, e2);
     const float det = rt_dot3(e1, pvec);
     if (det < RT_EPSILON) return;
@@ -96,6 +110,20 @@ __device__ __forceinline__ void tri_test(const RtSceneView &sv, uint32_t leaf, c
     }
 }
 
+// CheckTriangle (BVHRayTracing.cginc:41-76) on the record of sorted leaf `leaf`:
+// the triangle's own exact box with the reference's test, then
+// IntersectTriangle_MT97 on (v0, e1 = v1 - v0, e2 = v2 - v0) and the acceptance test.
+// Returns whether the box passed.
+__device__ __forceinline__ bool tri_test(const RtSceneView &sv, uint32_t leaf, const rt_f3 o, const rt_f3 d, const rt_f3 r, RtHitRec &h)
+{
+    const float4 *p = (const float4 *)(sv.leafTri + leaf);
+    const float4 a = p[0], b = p[1], c = p[2], e = p[3];
+    if (!box_hit(c.z, c.w, e.x, e.y, e.z, e.w, o, d, r)) return false;
+    const rt_f3 v0 = rt_mk3(a.x, a.y, a.z), e1 = rt_mk3(a.w, b.x, b.y), e2 = rt_mk3(b.z, b.w, c.x);
+    tri_test_values(v0, e1, e2, leaf, o, d, h);
+    return true;
+}
+
 __device__ __forceinline__ void flush_counters(const RtSceneView &sv, uint32_t rays, const uint32_t cnt[3], uint32_t hits)
 {
     uint32_t v[5] = {rays, cnt[0], cnt[1], cnt[2], hits};
@@ -110,10 +138,10 @@ __device__ __forceinline__ void flush_counters(const RtSceneView &sv, uint32_t r
 
 // Ray distribution: one cursor shared by all waves of the launch (zero at
 // launch); a wave draws as many rays as it has idle lanes.  Measured against a
-// static interleaved deal (no atomics at all: 8 % slower, the waves finish
-// unevenly) and against 64 cursors on separate cache lines (48 % slower: two
-// dependent round trips per draw); the single cursor is not a bottleneck here
-// because a draw covers 24-64 rays.
+// static interleaved deal (no atomics: 8 % slower, the waves finish unevenly),
+// against 64 cursors on separate cache lines (48 % slower: two dependent round
+// trips per draw) and against reserving 128..2048 rays per atomic (slower the
+// larger the reservation: short launches end unevenly).
 struct RayFeed {
     uint32_t *cursor;
     uint32_t total;
@@ -138,21 +166,27 @@ struct RayFeed {
 
 // Persistent traversal of `src.count()` rays by the waves of the launch (*cursor is 0 at launch).
 //   Src: uint32_t count(); void load(uint32_t i, rt_f3 &o, rt_f3 &d); void store(uint32_t i, const RtHitRec &h);
-// lds: TRV_LDS_WORDS words per block; this lane's stack entries are
-// lds[level * TRV_THREADS + tid], its pending triangles lds[(RT_STACK_DEPTH + k) * TRV_THREADS + tid].
+// lds: TRV_LDS_WORDS words per block; this lane's first TRV_STACK_LDS stack levels are
+// lds[level * TRV_THREADS + tid], its pending triangles lds[(TRV_STACK_LDS + k) * TRV_THREADS + tid];
+// stack levels from TRV_STACK_LDS up live in sv.stackSpill[(level - TRV_STACK_LDS) * lanes + global lane].
+// 20 words per lane let 8 waves per SIMD share the CU's 160 KB of LDS.
 template <bool COUNT, class Src>
 __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, uint32_t *__restrict__ cursor, uint32_t *lds)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt = (1ull << lane) - 1ull;
     uint32_t *stk = lds + threadIdx.x;
-    uint32_t *pend = lds + RT_STACK_DEPTH * TRV_THREADS + threadIdx.x;
+    uint32_t *pend = lds + TRV_STACK_LDS * TRV_THREADS + threadIdx.x;
+    const uint32_t spillLanes = gridDim.x * TRV_THREADS;
+    uint32_t *spill = sv.stackSpill + (blockIdx.x * TRV_THREADS + threadIdx.x);
     RayFeed feed;
     feed.init(cursor, src.count());
 
-    bool hasRay = false;
+    bool hasRay = false, odd = false;
     uint32_t rayIdx = 0, node = TRV_DONE, sp = 0, npend = 0;
     rt_f3 o = rt_splat3(0.0f), d = rt_splat3(0.0f), r = rt_splat3(0.0f);
+    RtRaySlab slab;
+    memset(&slab, 0, sizeof slab);
     RtHitRec h;
     h.t = rt_inf(); h.u = 0.0f; h.v = 0.0f; h.leaf = RT_INVALID;
     uint32_t cnt[3] = {0, 0, 0};
@@ -168,6 +202,8 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                 rayIdx = mine;
                 src.load(mine, o, d);
                 r = rt_mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                odd = rt_ray_needs_exact_walk(o, d);
+                slab = rt_ray_slab(sv.grid, o, r);
                 h.t = rt_inf(); h.u = 0.0f; h.v = 0.0f; h.leaf = RT_INVALID;
                 hasRay = true;
                 sp = 0;
@@ -190,24 +226,39 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
             const unsigned long long am = __ballot(act);
             if (am == 0ull) break;
             if (act) {
-                const float4 *np = (const float4 *)(sv.nodes + node);
-                const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-                const uint32_t l = __float_as_uint(q3.x), rr = __float_as_uint(q3.y);
-                const bool lLeaf = (l & RT_LEAF_BIT) != 0, rLeaf = (rr & RT_LEAF_BIT) != 0;
-                const bool hitL = box_hit(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, d, r);
-                const bool hitR = box_hit(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, d, r);
-                if (COUNT) {
-                    cnt[0] += (lLeaf ? 0u : 1u) + (rLeaf ? 0u : 1u);
-                    cnt[1] += (lLeaf ? 1u : 0u) + (rLeaf ? 1u : 0u);
-                    cnt[2] += ((lLeaf && hitL) ? 1u : 0u) + ((rLeaf && hitR) ? 1u : 0u);
+                uint32_t l, rr;
+                bool hitL, hitR;
+                if (__builtin_expect(!odd, 1)) {
+                    const uint4 *np = (const uint4 *)(sv.qnodes + node);
+                    uint4 qa = np[0], qb = np[1];
+                    // keep the fetch at two 16-byte loads per lane (the compiler would otherwise split the second)
+                    asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));
+                    l = qb.z;
+                    rr = qb.w;
+                    hitL = rt_slab_maybe(slab, qa.x, qa.y, qa.z);
+                    hitR = rt_slab_maybe(slab, qa.w, qb.x, qb.y);
+                } else {
+                    const float4 *np = (const float4 *)(sv.nodes + node);
+                    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                    l = __float_as_uint(q3.x);
+                    rr = __float_as_uint(q3.y);
+                    hitL = box_hit_exact(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, d);
+                    hitR = box_hit_exact(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, d);
                 }
+                const bool lLeaf = (l & RT_LEAF_BIT) != 0, rLeaf = (rr & RT_LEAF_BIT) != 0;
+                if (COUNT) cnt[0] += 2u;
                 if (lLeaf && hitL) { pend[npend * TRV_THREADS] = l & ~RT_LEAF_BIT; npend++; }
                 if (rLeaf && hitR) { pend[npend * TRV_THREADS] = rr & ~RT_LEAF_BIT; npend++; }
                 const bool goL = !lLeaf && hitL, goR = !rLeaf && hitR;
                 if (goR) {
                     if (goL) {
                         if (sp >= RT_STACK_DEPTH) { *sv.errorFlag = 1u; node = TRV_DONE; }
-                        else { stk[sp * TRV_THREADS] = l; sp++; node = rr; }
+                        else {
+                            if (sp < TRV_STACK_LDS) stk[sp * TRV_THREADS] = l;
+                            else spill[(size_t)(sp - TRV_STACK_LDS) * spillLanes] = l;
+                            sp++;
+                            node = rr;
+                        }
                     } else {
                         node = rr;
                     }
@@ -217,7 +268,7 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                     node = TRV_DONE;
                 } else {
                     sp--;
-                    node = stk[sp * TRV_THREADS];
+                    node = sp < TRV_STACK_LDS ? stk[sp * TRV_THREADS] : spill[(size_t)(sp - TRV_STACK_LDS) * spillLanes];
                 }
             }
             // a node step can queue two triangles: stop while there is still room for two
@@ -228,7 +279,10 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
 
         // ---- triangle phase: every lane tests its queued triangles in the order it met them
         for (uint32_t k = 0; __ballot(k < npend) != 0ull; ++k)
-            if (k < npend) tri_test(sv, pend[k * TRV_THREADS], o, d, h);
+            if (k < npend) {
+                const bool boxed = tri_test(sv, pend[k * TRV_THREADS], o, d, r, h);
+                if (COUNT) { cnt[1]++; cnt[2] += boxed ? 1u : 0u; }
+            }
         npend = 0;
 
         // ---- retire finished rays
@@ -272,28 +326,6 @@ __device__ __forceinline__ float row_bcastf(uint32_t x) { return __uint_as_float
 __device__ __forceinline__ uint32_t row_ballot(bool p, uint32_t rowShift)
 {
     return (uint32_t)(__ballot(p) >> rowShift) & 0xFFFFu;
-}
-
-__device__ __forceinline__ void tri_test_values(const rt_f3 v0, const rt_f3 e1, const rt_f3 e2, uint32_t leaf, const rt_f3 o,
-                                                const rt_f3 d, RtHitRec &h)
-{
-    const rt_f3 pvec = rt_cross3(d, e2);
-    const float det = rt_dot3(e1, pvec);
-    if (det < RT_EPSILON) return;
-    const float inv_det = 1.0f / det;
-    const rt_f3 tvec = rt_sub3(o, v0);
-    const float u = rt_dot3(tvec, pvec) * inv_det;
-    if (u < 0.0f || u > 1.0f) return;
-    const rt_f3 qvec = rt_cross3(tvec, e1);
-    const float v = rt_dot3(d, qvec) * inv_det;
-    if (v < 0.0f || u + v > 1.0f) return;
-    const float t = rt_dot3(e2, qvec) * inv_det;
-    if (t > 0.0f && t < h.t) {
-        h.t = t;
-        h.u = u;
-        h.v = v;
-        h.leaf = leaf;
-    }
 }
 
 // the packet's rays in `want` test sorted leaf `leaf`

@@ -188,6 +188,71 @@ def test_bvh_traversal_equals_brute_force(oracle):
     assert c["internalVisits"] >= c["rays"] and c["triTests"] <= c["leafVisits"]
 
 
+@pytest.mark.parametrize("name", ["cornell", "soup", "car", "dups", "far"])
+def test_grid_walk_returns_the_reference_walks_hits(oracle, name):
+    """The library walks 16-bit outward-rounded boxes with a may-pass test and keeps only the
+    triangle's own box exact.  That must not change a single hit: same triangle, same t/u/v bits
+    as the reference's walk, same number of triangles whose own box passed; it may only test
+    more boxes."""
+    if name == "cornell":
+        sc = scenes.cornell_box(32, 32, sphere_segments=24)
+        o, d = H.random_rays(30000, 11, -9, 14)
+    elif name == "soup":
+        sc = scenes.triangle_soup(30000, seed=5, width=32, height=32)
+        o, d = scenes.stress_rays(30000, seed=12)
+    elif name == "car":
+        sc = scenes.car_standin(32, 32, detail=0.05)
+        o, d = H.random_rays(30000, 13, -3, 3)
+    elif name == "dups":
+        sc = scenes.triangle_soup(3000, seed=7, width=32, height=32, extent=0.2, edge=0.3)   # many equal Morton codes
+        o, d = H.random_rays(20000, 14, -1, 1)
+    else:   # a scene far from the origin and much larger than its triangles: coarse grid cells
+        sc = scenes.triangle_soup(20000, seed=9, width=32, height=32, extent=120.0, edge=0.01)
+        o, _ = scenes.stress_rays(20000, seed=15)
+        rs = np.random.Generator(np.random.PCG64(16))      # aim at the triangles, they are too small to hit by chance
+        target = sc.vertices["position"][sc.indices.reshape(-1, 3)[rs.integers(0, 20000, len(o)), 0]]
+        d = target + rs.normal(scale=0.004, size=target.shape) - o
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    # degenerate directions take the exact walk
+    o = np.concatenate([o, np.tile(o[:1], (6, 1))])
+    d = np.concatenate([d, np.array([[0, 0, 1], [1, 0, 0], [0, -1, 0], [0, 0, 0], [np.nan, 0, 1], [0, 1e-30, 1]], np.float32)])
+    orc = oracle.Oracle(sc).build()
+    ok, grid, qboxes = orc.grid()
+    assert ok, "every box must fit the grid"
+    ref = orc.trace(o, d)
+    got = orc.trace(o, d, grid=True)
+    for k in ("triangle", "t", "u", "v"):
+        H.assert_bits_equal(got[k], ref[k], k)
+    assert got["counters"]["triTests"] == ref["counters"]["triTests"]
+    assert got["counters"]["hits"] == ref["counters"]["hits"]
+    assert (ref["triangle"] != 0xFFFFFFFF).sum() > 50
+
+
+def test_grid_boxes_contain_the_exact_boxes(oracle):
+    sc = scenes.car_standin(32, 32, detail=0.03)
+    orc = oracle.Oracle(sc).build()
+    ok, g, q = orc.grid()
+    assert ok
+    bvh = orc.readback_bvh()
+    org, step = g[:3], g[3:]
+    nodes, leaves = bvh["internal"], bvh["leaves"]
+    for side, off in (("left", 0), ("right", 3)):
+        child = nodes[side + "Node"]
+        is_leaf = nodes[side + "NodeType"] != 0        # RT_INTERNAL_NODE = 0
+        tri = bvh["sorted_index"][leaves["index"][np.where(is_leaf, child, 0)]]
+        mn = np.where(is_leaf[:, None], bvh["tri_aabb"]["min"][tri], bvh["bvh_data"]["min"][np.where(is_leaf, 0, child)])
+        mx = np.where(is_leaf[:, None], bvh["tri_aabb"]["max"][tri], bvh["bvh_data"]["max"][np.where(is_leaf, 0, child)])
+        w = q[:, off:off + 3]
+        lo = np.stack([w[:, 0] & 0xFFFF, w[:, 0] >> 16, w[:, 1] & 0xFFFF], 1)
+        hi = np.stack([w[:, 1] >> 16, w[:, 2] & 0xFFFF, w[:, 2] >> 16], 1)
+        plo = org + lo.astype(np.float32) * step      # float32 arithmetic, the walker's own expression
+        phi = org + hi.astype(np.float32) * step
+        assert plo.dtype == np.float32 and (plo <= mn).all() and (phi >= mx).all()
+        # ... and tight: one cell further in would cut into the exact box
+        assert ((org + (lo + 1).astype(np.float32) * step > mn) | (lo == 65535)).all()
+        assert ((org + np.maximum(hi.astype(np.int64) - 1, 0).astype(np.float32) * step < mx) | (hi == 0)).all()
+
+
 def test_backface_culling_and_single_triangle(oracle):
     sc = scenes.triangle_soup(2, seed=1)
     v = sc.vertices.copy()
