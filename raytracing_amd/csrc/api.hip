@@ -121,13 +121,13 @@ int rt_create(int device_id, RtContext **out_ctx)
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) ctx->numCU = cus;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void **)&ctx->dStats, 16 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void **)&ctx->dStats, 64 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&ctx->dErrorFlag, 4) != hipSuccess || hipMalloc((void **)&ctx->dQCount, RT_COUNTER_BLOCK_WORDS * 4) != hipSuccess ||
         hipMalloc((void **)&ctx->dStackSpill, (size_t)ctx->numCU * RT_SPILL_WORDS_PER_CU * 4) != hipSuccess) {
         delete ctx;
         return RT_E_DEVICE;
     }
-    (void)hipMemset(ctx->dStats, 0, 16 * sizeof(unsigned long long));
+    (void)hipMemset(ctx->dStats, 0, 64 * sizeof(unsigned long long));
     (void)hipMemset(ctx->dErrorFlag, 0, 4);
     (void)hipMemset(ctx->dQCount, 0, RT_COUNTER_BLOCK_WORDS * 4);
     *out_ctx = ctx;
@@ -522,7 +522,7 @@ int rt_reset_stats(RtContext *ctx)
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     rt_timer_resolve(ctx);
     ctx->timers.clear();
-    RT_HIP(ctx, hipMemset(ctx->dStats, 0, 16 * sizeof(unsigned long long)));
+    RT_HIP(ctx, hipMemset(ctx->dStats, 0, 64 * sizeof(unsigned long long)));
     return RT_OK;
 }
 
@@ -531,21 +531,32 @@ int rt_get_stats(RtContext *ctx, RtStats *out)
     RT_ENTER(ctx);
     if (!out) return rt_fail(ctx, RT_E_INVALID, "null stats");
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned long long h[16];   // [0..7] all launches but the shadow rays, [8..15] shadow-ray launches
+    unsigned long long h[40];   // [0..4] all launches but the shadow rays, [32..36] shadow-ray launches
     RT_HIP(ctx, hipMemcpy(h, ctx->dStats, sizeof h, hipMemcpyDeviceToHost));
-    out->rays = h[0] + h[8];
-    out->internalVisits = h[1] + h[9];
-    out->leafVisits = h[2] + h[10];
-    out->triTests = h[3] + h[11];
-    out->hits = h[4] + h[12];
+    out->rays = h[0] + h[32];
+    out->internalVisits = h[1] + h[33];
+    out->leafVisits = h[2] + h[34];
+    out->triTests = h[3] + h[35];
+    out->hits = h[4] + h[36];
     out->paths = h[5];
-    out->shadowRays = h[8];
-    out->shadowInternalVisits = h[9];
-    out->shadowLeafVisits = h[10];
-    out->shadowTriTests = h[11];
-    out->shadowHits = h[12];
+    out->shadowRays = h[32];
+    out->shadowInternalVisits = h[33];
+    out->shadowLeafVisits = h[34];
+    out->shadowTriTests = h[35];
+    out->shadowHits = h[36];
     out->buildMs = ctx->buildMs;
     out->renderMs = ctx->renderMs;
+    return RT_OK;
+}
+
+/* Phase profile of the one-ray-per-lane walker (library built with -DTRV_PROFILE): 4 clock sums
+ * (refill, node, triangle, retire) and 6 counts, summed over waves.  Not part of rtcore.h. */
+int rt_debug_walker_profile(RtContext *ctx, unsigned long long path_rays[16], unsigned long long shadow_rays[16])
+{
+    RT_ENTER(ctx);
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipMemcpy(path_rays, ctx->dStats + 16, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    RT_HIP(ctx, hipMemcpy(shadow_rays, ctx->dStats + 48, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

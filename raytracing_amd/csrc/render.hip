@@ -131,7 +131,7 @@ __global__ __launch_bounds__(TRV_THREADS) void k_traverse(RtSceneView sv, Src sr
 }
 
 template <bool COUNT, class Src>
-__global__ __launch_bounds__(TRV_THREADS) void k_traverse_packets(RtSceneView sv, Src src, uint32_t *__restrict__ cursor)
+__global__ __launch_bounds__(PKT_THREADS) void k_traverse_packets(RtSceneView sv, Src src, uint32_t *__restrict__ cursor)
 {
     __shared__ uint32_t lds[PKT_LDS_WORDS];
     traverse_packets<COUNT>(sv, src, cursor, lds);
@@ -549,20 +549,12 @@ uint32_t rt_batch_frames(RtContext *ctx, uint32_t wanted)
     return f ? f : 1;
 }
 
-// Persistent launch: enough resident waves to fill the chip; every wave pulls
-// rays from the shared cursor until none are left.
+// Persistent launch: enough resident waves to fill the chip; every wave pulls rays from the
+// shared cursor until none are left.
 template <class Src>
 static void launch_traverse(RtContext *ctx, const RtSceneView &sv, const Src &src, uint32_t *cursor, uint32_t maxRays, const char *name)
 {
-    static int perCU[2] = {0, 0};
-    const int ci = ctx->countersOn ? 1 : 0;
-    if (perCU[ci] == 0) {
-        int n = 0;
-        hipError_t e = ctx->countersOn ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse<true, Src>, TRV_THREADS, 0)
-                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse<false, Src>, TRV_THREADS, 0);
-        perCU[ci] = (e == hipSuccess && n > 0) ? (n < TRV_MAX_BLOCKS_PER_CU ? n : TRV_MAX_BLOCKS_PER_CU) : 4;
-    }
-    uint32_t blocks = (uint32_t)ctx->numCU * (uint32_t)perCU[ci];
+    uint32_t blocks = (uint32_t)ctx->numCU * TRV_BLOCKS_PER_CU;
     const uint32_t need = (maxRays + TRV_THREADS - 1) / TRV_THREADS;
     if (need < blocks) blocks = need ? need : 1;
     rt_timer_begin(ctx, name);
@@ -580,16 +572,16 @@ static void launch_traverse_packets(RtContext *ctx, const RtSceneView &sv, const
     if (perCU[ci] == 0) {
         int n = 0;
         hipError_t e = ctx->countersOn
-            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_packets<true, Src>, TRV_THREADS, 0)
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_packets<false, Src>, TRV_THREADS, 0);
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_packets<true, Src>, PKT_THREADS, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse_packets<false, Src>, PKT_THREADS, 0);
         perCU[ci] = (e == hipSuccess && n > 0) ? n : 4;
     }
     uint32_t blocks = (uint32_t)ctx->numCU * (uint32_t)perCU[ci];
-    const uint32_t need = (maxRays + TRV_THREADS - 1) / TRV_THREADS;
+    const uint32_t need = (maxRays + PKT_THREADS - 1) / PKT_THREADS;
     if (need < blocks) blocks = need ? need : 1;
     rt_timer_begin(ctx, name);
-    if (ctx->countersOn) hipLaunchKernelGGL((k_traverse_packets<true, Src>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, src, cursor);
-    else hipLaunchKernelGGL((k_traverse_packets<false, Src>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, src, cursor);
+    if (ctx->countersOn) hipLaunchKernelGGL((k_traverse_packets<true, Src>), dim3(blocks), dim3(PKT_THREADS), 0, ctx->stream, sv, src, cursor);
+    else hipLaunchKernelGGL((k_traverse_packets<false, Src>), dim3(blocks), dim3(PKT_THREADS), 0, ctx->stream, sv, src, cursor);
     rt_timer_end(ctx);
 }
 
@@ -612,7 +604,7 @@ static void launch_sm_setup(RtContext *ctx, const RtSceneView &sv, uint32_t tota
 static void launch_shadow_rays(RtContext *ctx, const RtSceneView &sceneView, uint32_t total)
 {
     RtSceneView sv = sceneView;
-    sv.stats = ctx->dStats + 8;                  // counted apart from the other traversals
+    sv.stats = ctx->dStats + 32;                 // counted apart from the other traversals
     const RtParams &P = ctx->params;
     ShadowSrc sh;
     sh.smq = ctx->dSmQueue;

@@ -119,7 +119,7 @@ struct RtPendingEvent {
 };
 
 #define RT_COUNTER_BLOCK_WORDS 64   // queue counts (dQCount)
-#define RT_SPILL_WORDS_PER_CU (8 * 256 * RT_STACK_DEPTH)   // room for every stack level of 8 blocks of 256 lanes
+#define RT_SPILL_WORDS_PER_CU (2048 * RT_STACK_DEPTH)   // room for every stack level of 2048 lanes per CU
 
 struct RtContext {
     int device = 0;
@@ -180,7 +180,7 @@ struct RtContext {
 
     // stats / timing
     uint32_t *dStackSpill = nullptr;     // numCU * 8 blocks * 256 lanes * (RT_STACK_DEPTH - TRV_STACK_LDS) words
-    unsigned long long *dStats = nullptr; // 2 banks of 8 x u64
+    unsigned long long *dStats = nullptr; // 64 x u64: counters [0..4] / [32..36] (shadow rays), walker profile [16..25] / [48..57]
     uint32_t *dErrorFlag = nullptr;
     bool countersOn = false;
     bool timingOn = false;

@@ -35,18 +35,24 @@
 #include "rt_internal.h"
 
 #define TRV_THREADS 256
+#define PKT_THREADS 256
 #ifndef TRV_PEND_CAP
-#define TRV_PEND_CAP 4          // queued triangle tests per lane
+#define TRV_PEND_CAP 6          // queued triangle tests per lane
 #endif
 #ifndef TRV_STACK_LDS
 #define TRV_STACK_LDS 16        // stack levels kept in LDS; deeper levels spill to HBM (rare)
 #endif
-#define TRV_MAX_BLOCKS_PER_CU 8
-#define TRV_NODE_BURST 48       // node steps between two triangle batches
+#ifndef TRV_REFILL_MIN
 #define TRV_REFILL_MIN 24       // refill when at least this many lanes are idle
-#define TRV_EARLY_OUT 40        // leave a burst when this many lanes have nothing to walk
+#endif
+#ifndef TRV_WALK_NUM
+#define TRV_WALK_NUM 3u         // leave the node phase when fewer than NUM/DEN of the lanes that still
+#define TRV_WALK_DEN 4u         // have nodes to visit can go on (the rest wait for triangle tests)
+#endif
 #define TRV_DONE 0xFFFFFFFFu
 #define TRV_LDS_WORDS ((TRV_STACK_LDS + TRV_PEND_CAP) * TRV_THREADS)
+static_assert(TRV_LDS_WORDS * 4 * 6 <= 160 * 1024, "six blocks per CU must fit the LDS");
+#define TRV_BLOCKS_PER_CU 8u    // 20 KB of LDS per block: eight blocks fill a CU's 160 KB (registers allow six)
 
 // The reference's slab test, verbatim: true divisions, min/max that return the
 // non-NaN operand (v_min_f32 / v_max_f32 in IEEE mode).
@@ -137,30 +143,63 @@ __device__ __forceinline__ void flush_counters(const RtSceneView &sv, uint32_t r
 }
 
 // Ray distribution: one cursor shared by all waves of the launch (zero at
-// launch); a wave draws as many rays as it has idle lanes.  Measured against a
-// static interleaved deal (no atomics: 8 % slower, the waves finish unevenly),
-// against 64 cursors on separate cache lines (48 % slower: two dependent round
-// trips per draw) and against reserving 128..2048 rays per atomic (slower the
-// larger the reservation: short launches end unevenly).
+// launch).  A wave reserves a run of consecutive rays with one atomic and deals
+// them to its idle lanes over the following refills.  Atomics on one address
+// complete at roughly one per 10 ns for the whole device: one atomic per refill
+// (24-64 rays) held a 190 M-ray launch at 2.8 G rays/s.  Reservations shrink
+// with the work that is left (short launches and the end of long ones would
+// otherwise finish unevenly: fixed runs of 2048 rays tripled the time of the
+// small bounce launches).
+#ifndef TRV_CHUNK_MAX
+#define TRV_CHUNK_MAX 512u      // most rays a wave reserves with one atomic
+#endif
+#ifndef TRV_CHUNK_MIN
+#define TRV_CHUNK_MIN 64u
+#endif
+#ifndef TRV_CHUNK_SHARE
+#define TRV_CHUNK_SHARE 8u      // a reservation is at most 1/SHARE of an even share of the rays that are left
+#endif
 struct RayFeed {
     uint32_t *cursor;
-    uint32_t total;
-    bool exhausted;                              // wave-uniform
+    uint32_t total, next, end, chunk, waves2;    // wave-uniform
+    bool lastChunk, exhausted;
+    __device__ __forceinline__ uint32_t chunk_for(uint32_t remaining) const
+    {
+        // guided self-scheduling: big reservations while there is plenty of work, small ones
+        // towards the end so that the waves finish together
+        // (0 = no more reserving: from there on a wave draws exactly what its idle lanes need)
+        const uint32_t c = (remaining / waves2) & ~15u;
+        return c < TRV_CHUNK_MIN ? 0u : (c > TRV_CHUNK_MAX ? TRV_CHUNK_MAX : c);
+    }
     __device__ __forceinline__ void init(uint32_t *c, uint32_t n)
     {
         cursor = c;
         total = n;
-        exhausted = false;
+        next = end = 0;
+        waves2 = gridDim.x * (blockDim.x >> 6) * TRV_CHUNK_SHARE;
+        chunk = chunk_for(n);
+        lastChunk = false;
+        exhausted = n == 0;
     }
-    // Wave-uniform call: hands `want` rays to the lanes with rank 0..want-1 (`rank` = this
+    // Wave-uniform call: hands up to `want` rays to the lanes with rank 0..want-1 (`rank` = this
     // lane's position among the asking lanes).  Returns this lane's ray or TRV_DONE.
     __device__ __forceinline__ uint32_t draw(uint32_t want, uint32_t rank)
     {
-        uint32_t base = 0;
-        if ((threadIdx.x & 63u) == 0) base = atomicAdd(cursor, want);
-        base = __shfl(base, 0, 64);
-        if (base + want >= total) exhausted = true;
-        return (rank < want && base + rank < total) ? base + rank : TRV_DONE;
+        if (next == end && !lastChunk) {
+            const uint32_t take = chunk ? chunk : want;
+            uint32_t base = 0;
+            if ((threadIdx.x & 63u) == 0) base = atomicAdd(cursor, take);
+            base = __shfl(base, 0, 64);
+            next = base < total ? base : total;
+            end = total - next < take ? total : next + take;
+            lastChunk = end == total;
+            chunk = chunk_for(total - end);
+        }
+        const uint32_t n = want < end - next ? want : end - next;
+        const uint32_t mine = rank < n ? next + rank : TRV_DONE;
+        next += n;
+        exhausted = lastChunk && next == end;
+        return mine;
     }
 };
 
@@ -169,7 +208,6 @@ struct RayFeed {
 // lds: TRV_LDS_WORDS words per block; this lane's first TRV_STACK_LDS stack levels are
 // lds[level * TRV_THREADS + tid], its pending triangles lds[(TRV_STACK_LDS + k) * TRV_THREADS + tid];
 // stack levels from TRV_STACK_LDS up live in sv.stackSpill[(level - TRV_STACK_LDS) * lanes + global lane].
-// 20 words per lane let 8 waves per SIMD share the CU's 160 KB of LDS.
 template <bool COUNT, class Src>
 __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, uint32_t *__restrict__ cursor, uint32_t *lds)
 {
@@ -192,6 +230,13 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
     uint32_t cnt[3] = {0, 0, 0};
     uint32_t nRays = 0, nHits = 0;
 
+#ifdef TRV_PROFILE
+    // phase clocks of this wave (shader clock), reported through sv.stats[16..]
+    unsigned long long pT[4] = {0, 0, 0, 0}, pN[6] = {0, 0, 0, 0, 0, 0}, pS[3] = {0, 0, 0}, pMark = clock64();
+#define TRV_PHASE(k) { const unsigned long long now_ = clock64(); pT[k] += now_ - pMark; pMark = now_; }
+#else
+#define TRV_PHASE(k)
+#endif
     for (;;) {
         // ---- refill idle lanes: ballot, prefix count, one atomic per wave
         const unsigned long long idle = __ballot(!hasRay);
@@ -206,7 +251,8 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                 slab = rt_ray_slab(sv.grid, o, r);
                 h.t = rt_inf(); h.u = 0.0f; h.v = 0.0f; h.leaf = RT_INVALID;
                 hasRay = true;
-                sp = 0;
+                stk[0] = TRV_DONE;                             // what the last pop of a ray returns
+                sp = 1;
                 npend = 0;
                 node = TRV_DONE;
                 if (COUNT) nRays++;
@@ -219,12 +265,28 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
             }
         }
         if (__ballot(hasRay) == 0ull) break;
+        TRV_PHASE(0)
+#ifdef TRV_PROFILE
+        pN[0]++;
+#endif
 
-        // ---- node phase: walk the tree, queue triangles whose box passes
-        for (int it = 0; it < TRV_NODE_BURST; ++it) {
-            const bool act = hasRay && node != TRV_DONE;
+        // ---- node phase: walk the tree, queue triangles whose box passes.  A lane whose
+        // pending list has no room for two more entries waits; the phase ends when too few
+        // lanes are still walking (the others wait for triangle tests, a refill or retirement).
+        for (;;) {
+            const bool act = node != TRV_DONE && npend <= TRV_PEND_CAP - 2;
             const unsigned long long am = __ballot(act);
-            if (am == 0ull) break;
+            const uint32_t nAct = (uint32_t)__popcll(am);
+            const uint32_t nBusy = (uint32_t)__popcll(__ballot(node != TRV_DONE));
+            if (nAct == 0u || nAct * TRV_WALK_DEN < nBusy * TRV_WALK_NUM || (!feed.exhausted && nBusy < 64u - TRV_REFILL_MIN)) break;
+#ifdef TRV_PROFILE
+            pN[1]++;
+            pN[2] += (unsigned long long)nAct;
+#endif
+#ifdef TRV_PROFILE
+            const unsigned long long q0_ = clock64();
+            unsigned long long q1_ = q0_, q2_ = q0_;
+#endif
             if (act) {
                 uint32_t l, rr;
                 bool hitL, hitR;
@@ -233,10 +295,19 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                     uint4 qa = np[0], qb = np[1];
                     // keep the fetch at two 16-byte loads per lane (the compiler would otherwise split the second)
                     asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));
+#ifdef TRV_PROFILE
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    asm volatile("" : "+v"(qa.x), "+v"(qa.y), "+v"(qa.z), "+v"(qa.w));
+                    q1_ = clock64();
+#endif
                     l = qb.z;
                     rr = qb.w;
                     hitL = rt_slab_maybe(slab, qa.x, qa.y, qa.z);
                     hitR = rt_slab_maybe(slab, qa.w, qb.x, qb.y);
+#ifdef TRV_PROFILE
+                    asm volatile("" :: "s"(__ballot(hitL)), "s"(__ballot(hitR)));
+                    q2_ = clock64();
+#endif
                 } else {
                     const float4 *np = (const float4 *)(sv.nodes + node);
                     const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
@@ -247,43 +318,56 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                 }
                 const bool lLeaf = (l & RT_LEAF_BIT) != 0, rLeaf = (rr & RT_LEAF_BIT) != 0;
                 if (COUNT) cnt[0] += 2u;
-                if (lLeaf && hitL) { pend[npend * TRV_THREADS] = l & ~RT_LEAF_BIT; npend++; }
-                if (rLeaf && hitR) { pend[npend * TRV_THREADS] = rr & ~RT_LEAF_BIT; npend++; }
+                // Straight-line bookkeeping: every store below happens whether or not it is needed
+                // (a slot past the end of a list is scratch), only the counters are conditional.
+                pend[npend * TRV_THREADS] = l & ~RT_LEAF_BIT;
+                npend += (lLeaf && hitL) ? 1u : 0u;
+                pend[npend * TRV_THREADS] = rr & ~RT_LEAF_BIT;
+                npend += (rLeaf && hitR) ? 1u : 0u;
                 const bool goL = !lLeaf && hitL, goR = !rLeaf && hitR;
-                if (goR) {
-                    if (goL) {
-                        if (sp >= RT_STACK_DEPTH) { *sv.errorFlag = 1u; node = TRV_DONE; }
-                        else {
-                            if (sp < TRV_STACK_LDS) stk[sp * TRV_THREADS] = l;
-                            else spill[(size_t)(sp - TRV_STACK_LDS) * spillLanes] = l;
-                            sp++;
-                            node = rr;
-                        }
-                    } else {
-                        node = rr;
+                if (__builtin_expect(sp < TRV_STACK_LDS, 1)) {
+                    const uint32_t below = stk[(sp - 1u) * TRV_THREADS];   // level 0 holds TRV_DONE
+                    stk[sp * TRV_THREADS] = l;                           // right first, left later
+                    const bool both = goL && goR, none = !(goL || goR);
+                    node = goR ? rr : l;
+                    node = none ? below : node;
+                    sp += both ? 1u : 0u;
+                    sp -= none ? 1u : 0u;
+                } else {                                                 // deep levels live in HBM
+                    node = goR ? rr : l;
+                    if (goL && goR) {
+                        if (sp < RT_STACK_DEPTH) spill[(size_t)(sp - TRV_STACK_LDS) * spillLanes] = l;
+                        else { *sv.errorFlag = 1u; sp = 0; }             // next pop ends the ray
+                        sp++;
                     }
-                } else if (goL) {
-                    node = l;
-                } else if (sp == 0) {
-                    node = TRV_DONE;
-                } else {
-                    sp--;
-                    node = sp < TRV_STACK_LDS ? stk[sp * TRV_THREADS] : spill[(size_t)(sp - TRV_STACK_LDS) * spillLanes];
+                    if (!(goL || goR)) {
+                        sp--;
+                        node = sp < TRV_STACK_LDS ? stk[sp * TRV_THREADS] : spill[(size_t)(sp - TRV_STACK_LDS) * spillLanes];
+                    }
                 }
             }
-            // a node step can queue two triangles: stop while there is still room for two
-            if (__ballot(npend > TRV_PEND_CAP - 2) != 0ull) break;
-            // many lanes finished: leave early so that they can be refilled
-            if (!feed.exhausted && (uint32_t)__popcll(__ballot(!hasRay || node == TRV_DONE)) >= (uint32_t)TRV_EARLY_OUT) break;
+#ifdef TRV_PROFILE
+            {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                const unsigned long long q3_ = clock64();
+                pS[0] += q1_ - q0_; pS[1] += q2_ - q1_; pS[2] += q3_ - q2_;
+            }
+#endif
         }
 
+        TRV_PHASE(1)
         // ---- triangle phase: every lane tests its queued triangles in the order it met them
         for (uint32_t k = 0; __ballot(k < npend) != 0ull; ++k)
+#ifdef TRV_PROFILE
+            if (pN[3]++, pN[4] += (unsigned long long)__popcll(__ballot(k < npend)), k < npend) {
+#else
             if (k < npend) {
+#endif
                 const bool boxed = tri_test(sv, pend[k * TRV_THREADS], o, d, r, h);
                 if (COUNT) { cnt[1]++; cnt[2] += boxed ? 1u : 0u; }
             }
         npend = 0;
+        TRV_PHASE(2)
 
         // ---- retire finished rays
         if (hasRay && node == TRV_DONE) {
@@ -291,7 +375,15 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
             if (COUNT && h.leaf != RT_INVALID) nHits++;
             hasRay = false;
         }
+        TRV_PHASE(3)
     }
+#ifdef TRV_PROFILE
+    if (lane == 0) {
+        for (int k = 0; k < 4; ++k) atomicAdd(&sv.stats[16 + k], pT[k]);
+        for (int k = 0; k < 6; ++k) atomicAdd(&sv.stats[20 + k], pN[k]);
+        for (int k = 0; k < 3; ++k) atomicAdd(&sv.stats[26 + k], pS[k]);
+    }
+#endif
     if (COUNT) flush_counters(sv, nRays, cnt, nHits);
 }
 
@@ -312,7 +404,7 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
 // needed.
 #define PKT_WIDTH 16u
 #define PKT_STACK_WORDS (2 * RT_STACK_DEPTH)                       // (node, ray set) per level
-#define PKT_LDS_WORDS (PKT_STACK_WORDS * (TRV_THREADS / PKT_WIDTH))
+#define PKT_LDS_WORDS (PKT_STACK_WORDS * (PKT_THREADS / PKT_WIDTH))
 
 template <int J>
 __device__ __forceinline__ uint32_t row_bcast(uint32_t x)           // lane J of each 16-lane row -> the whole row
