@@ -220,8 +220,8 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
     RayFeed feed;
     feed.init(cursor, src.count());
 
-    bool hasRay = false, odd = false;
-    uint32_t rayIdx = 0, node = TRV_DONE, sp = 0, npend = 0;
+    bool hasRay = false, odd = false, popped = false;
+    uint32_t rayIdx = 0, node = TRV_DONE, sp = 0, npend = 0, tos = TRV_DONE, below = TRV_DONE;
     rt_f3 o = rt_splat3(0.0f), d = rt_splat3(0.0f), r = rt_splat3(0.0f);
     RtRaySlab slab;
     memset(&slab, 0, sizeof slab);
@@ -253,6 +253,8 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                 hasRay = true;
                 stk[0] = TRV_DONE;                             // what the last pop of a ray returns
                 sp = 1;
+                tos = TRV_DONE;
+                popped = false;
                 npend = 0;
                 node = TRV_DONE;
                 if (COUNT) nRays++;
@@ -293,6 +295,8 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                 if (__builtin_expect(!odd, 1)) {
                     const uint4 *np = (const uint4 *)(sv.qnodes + node);
                     uint4 qa = np[0], qb = np[1];
+                    tos = popped ? below : tos;                          // after the loads are on their way
+                    popped = false;
                     // keep the fetch at two 16-byte loads per lane (the compiler would otherwise split the second)
                     asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));
 #ifdef TRV_PROFILE
@@ -311,6 +315,8 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                 } else {
                     const float4 *np = (const float4 *)(sv.nodes + node);
                     const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                    tos = popped ? below : tos;
+                    popped = false;
                     l = __float_as_uint(q3.x);
                     rr = __float_as_uint(q3.y);
                     hitL = box_hit_exact(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, d);
@@ -326,23 +332,36 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                 npend += (rLeaf && hitR) ? 1u : 0u;
                 const bool goL = !lLeaf && hitL, goR = !rLeaf && hitR;
                 if (__builtin_expect(sp < TRV_STACK_LDS, 1)) {
-                    const uint32_t below = stk[(sp - 1u) * TRV_THREADS];   // level 0 holds TRV_DONE
+                    // `tos` mirrors level sp-1 in a register, so a pop needs no LDS round trip before
+                    // the next node can be fetched; the level below is read now and taken over at the
+                    // start of this lane's next step (level 0 holds TRV_DONE).
                     stk[sp * TRV_THREADS] = l;                           // right first, left later
+                    below = stk[(sp > 1u ? sp - 2u : 0u) * TRV_THREADS];
                     const bool both = goL && goR, none = !(goL || goR);
                     node = goR ? rr : l;
-                    node = none ? below : node;
+                    node = none ? tos : node;
+                    tos = both ? l : tos;
+                    popped = none;
                     sp += both ? 1u : 0u;
                     sp -= none ? 1u : 0u;
                 } else {                                                 // deep levels live in HBM
                     node = goR ? rr : l;
                     if (goL && goR) {
-                        if (sp < RT_STACK_DEPTH) spill[(size_t)(sp - TRV_STACK_LDS) * spillLanes] = l;
-                        else { *sv.errorFlag = 1u; sp = 0; }             // next pop ends the ray
-                        sp++;
-                    }
-                    if (!(goL || goR)) {
+                        if (sp < RT_STACK_DEPTH) {
+                            spill[(size_t)(sp - TRV_STACK_LDS) * spillLanes] = l;
+                            sp++;
+                            tos = l;
+                        } else {                                         // deeper than any tree the build makes
+                            *sv.errorFlag = 1u;
+                            node = TRV_DONE;
+                            sp = 1;
+                            tos = TRV_DONE;
+                        }
+                    } else if (!(goL || goR)) {
+                        node = tos;
                         sp--;
-                        node = sp < TRV_STACK_LDS ? stk[sp * TRV_THREADS] : spill[(size_t)(sp - TRV_STACK_LDS) * spillLanes];
+                        const uint32_t lvl = sp ? sp - 1u : 0u;
+                        tos = lvl < TRV_STACK_LDS ? stk[lvl * TRV_THREADS] : spill[(size_t)(lvl - TRV_STACK_LDS) * spillLanes];
                     }
                 }
             }
