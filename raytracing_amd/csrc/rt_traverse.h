@@ -37,7 +37,7 @@
 #define TRV_THREADS 256
 #define PKT_THREADS 256
 #ifndef TRV_PEND_CAP
-#define TRV_PEND_CAP 6          // queued triangle tests per lane
+#define TRV_PEND_CAP 10         // queued triangle tests per lane
 #endif
 #ifndef TRV_STACK_LDS
 #define TRV_STACK_LDS 16        // stack levels kept in LDS; deeper levels spill to HBM (rare)
@@ -94,39 +94,56 @@ __device__ __forceinline__ bool box_hit(float bminx, float bminy, float bminz, f
 }
 
 // IntersectTriangle_MT97 + the acceptance test of CheckTriangle.
-__device__ __forceinline__ void tri_test_values(const rt_f3 v0, const rt_f3 e1, const rt_f3 e2, uint32_t leaf, const rt_f3 o,
+// (returns whether h was replaced)
+__device__ __forceinline__ bool tri_test_values(const rt_f3 v0, const rt_f3 e1, const rt_f3 e2, uint32_t leaf, const rt_f3 o,
                                                 const rt_f3 d, RtHitRec &h)
 {
     const rt_f3 pvec = rt_cross3(d, e2);
     const float det = rt_dot3(e1, pvec);
-    if (det < RT_EPSILON) return;
+    if (det < RT_EPSILON) return false;
     const float inv_det = 1.0f / det;
     const rt_f3 tvec = rt_sub3(o, v0);
     const float u = rt_dot3(tvec, pvec) * inv_det;
-    if (u < 0.0f || u > 1.0f) return;
+    if (u < 0.0f || u > 1.0f) return false;
     const rt_f3 qvec = rt_cross3(tvec, e1);
     const float v = rt_dot3(d, qvec) * inv_det;
-    if (v < 0.0f || u + v > 1.0f) return;
+    if (v < 0.0f || u + v > 1.0f) return false;
     const float t = rt_dot3(e2, qvec) * inv_det;
     if (t > 0.0f && t < h.t) {
         h.t = t;
         h.u = u;
         h.v = v;
         h.leaf = leaf;
+        return true;
     }
+    return false;
 }
 
 // CheckTriangle (BVHRayTracing.cginc:41-76) on the record of sorted leaf `leaf`:
 // the triangle's own exact box with the reference's test, then
 // IntersectTriangle_MT97 on (v0, e1 = v1 - v0, e2 = v2 - v0) and the acceptance test.
-// Returns whether the box passed.
+// Returns whether the box passed (needed for the work counters only).
+// A triangle changes the hit only if BOTH tests pass, so without counters the
+// cheaper-to-fail one runs first: Moller-Trumbore rejects nearly every candidate,
+// and the box (a fourth 16-byte load and the slab test) is looked at only for a
+// triangle that would otherwise be accepted.
+template <bool COUNT>
 __device__ __forceinline__ bool tri_test(const RtSceneView &sv, uint32_t leaf, const rt_f3 o, const rt_f3 d, const rt_f3 r, RtHitRec &h)
 {
     const float4 *p = (const float4 *)(sv.leafTri + leaf);
-    const float4 a = p[0], b = p[1], c = p[2], e = p[3];
-    if (!box_hit(c.z, c.w, e.x, e.y, e.z, e.w, o, d, r)) return false;
+    const float4 a = p[0], b = p[1], c = p[2];
     const rt_f3 v0 = rt_mk3(a.x, a.y, a.z), e1 = rt_mk3(a.w, b.x, b.y), e2 = rt_mk3(b.z, b.w, c.x);
-    tri_test_values(v0, e1, e2, leaf, o, d, h);
+    if (COUNT) {
+        const float4 e = p[3];
+        if (!box_hit(c.z, c.w, e.x, e.y, e.z, e.w, o, d, r)) return false;
+        tri_test_values(v0, e1, e2, leaf, o, d, h);
+        return true;
+    }
+    RtHitRec cand = h;
+    if (tri_test_values(v0, e1, e2, leaf, o, d, cand)) {              // Moller-Trumbore would accept it
+        const float4 e = p[3];
+        if (box_hit(c.z, c.w, e.x, e.y, e.z, e.w, o, d, r)) h = cand;
+    }
     return true;
 }
 
@@ -382,7 +399,7 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
 #else
             if (k < npend) {
 #endif
-                const bool boxed = tri_test(sv, pend[k * TRV_THREADS], o, d, r, h);
+                const bool boxed = tri_test<COUNT>(sv, pend[k * TRV_THREADS], o, d, r, h);
                 if (COUNT) { cnt[1]++; cnt[2] += boxed ? 1u : 0u; }
             }
         npend = 0;
