@@ -494,7 +494,7 @@ int rt_set_option(RtContext *ctx, int option, int value)
     case RT_OPT_PACKET_PRIMARY: ctx->optPacketPrimary = value != 0; return RT_OK;
     case RT_OPT_PACKET_TRACE: ctx->optPacketTrace = value != 0; return RT_OK;
     case RT_OPT_BATCH_FRAMES:
-        if (value < 1 || value > 8) return rt_fail(ctx, RT_E_INVALID, "RT_OPT_BATCH_FRAMES must be 1..8");
+        if (value < 0 || value > 64) return rt_fail(ctx, RT_E_INVALID, "RT_OPT_BATCH_FRAMES must be 0..64");
         ctx->optBatchFrames = (uint32_t)value;
         return RT_OK;
     default: return rt_fail(ctx, RT_E_INVALID, "unknown option");

@@ -474,8 +474,8 @@ RtSceneView rt_scene_view(RtContext *ctx)
 #define CNT_FETCH_TRACE 26
 #define CNT_WORDS 32
 static_assert(CNT_WORDS <= RT_COUNTER_BLOCK_WORDS, "counter block too small");
-#define RT_MAX_BATCH 8u
-#define RT_MAX_PATH_SLOTS (96u << 20)
+#define RT_MAX_BATCH 64u
+#define RT_BATCH_PATH_SLOTS (1u << 24)   // frames in flight are chosen so that a launch covers about this many paths
 
 void rt_free_render(RtContext *ctx)
 {
@@ -542,11 +542,12 @@ int rt_alloc_render(RtContext *ctx)
 
 uint32_t rt_batch_frames(RtContext *ctx, uint32_t wanted)
 {
+    // Enough frames in flight for ~16 M paths per launch: 8 frames of a whole 1080p image, 64 frames
+    // of an eighth of it (one rank of eight), 2 of a 4K image.  optBatchFrames = 0 means this rule.
     const uint32_t n = ctx->tile.nSlots ? ctx->tile.nSlots : 1;
-    const uint32_t cap = ctx->optBatchFrames < RT_MAX_BATCH ? ctx->optBatchFrames : RT_MAX_BATCH;
-    uint32_t f = wanted < cap ? wanted : cap;
-    while (f > 1 && (uint64_t)f * n > RT_MAX_PATH_SLOTS) --f;
-    return f ? f : 1;
+    uint32_t cap = ctx->optBatchFrames ? ctx->optBatchFrames : RT_BATCH_PATH_SLOTS / n;
+    cap = cap < 1u ? 1u : (cap > RT_MAX_BATCH ? RT_MAX_BATCH : cap);
+    return wanted < cap ? (wanted ? wanted : 1u) : cap;
 }
 
 // Persistent launch: enough resident waves to fill the chip; every wave pulls rays from the

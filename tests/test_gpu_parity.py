@@ -222,7 +222,13 @@ def test_batched_frames_equal_frame_by_frame_driver(core, flags_clear):
     core.bvh_build()
     core.set_params(p)
     core.set_dirty()
+    core.set_option(wire.OPT_BATCH_FRAMES, 8)
     core.render_frames(seeds)
+    by_eight = core.readback(wire.IMAGE_CONVERGED)
+    core.set_option(wire.OPT_BATCH_FRAMES, 0)     # default: as many frames in flight as fit the path budget (all 11 here)
+    core.set_dirty()
+    core.render_frames(seeds)
+    H.assert_bits_equal(by_eight, core.readback(wire.IMAGE_CONVERGED), "batches of 8 + 3 vs one batch of 11")
     a = core.readback(wire.IMAGE_CONVERGED)
     a_rt = core.readback(wire.IMAGE_RT)
     a_sm = core.readback(wire.IMAGE_SHADOWMAP)
