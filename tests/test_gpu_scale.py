@@ -147,3 +147,139 @@ def test_traversal_stress_10m(core, oracle, soup10m):
     H.assert_bits_equal(got["triangle"][pick], want["triangle"], "stress first-hit ids")
     H.assert_bits_equal(got["t"][pick], want["t"], "stress distances")
     print(f"\n10M soup: {n} incoherent rays in {ms:.2f} ms = {n / ms / 1e3:.1f} Mrays/s")
+
+
+# ------------------------------------------------------------------ BASELINE configurations
+def _rmse(a, b):
+    return float(np.sqrt(np.mean((a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)) ** 2)))
+
+
+def test_config1_cornell_256x256_16spp_against_checker(core, oracle):
+    """The reference's own CPU-runnable case, complete: Cornell box, 256 x 256, 16 frames, MIS,
+    per-frame seeds = the first 16 floats of PCG32(1).  Per-pixel relative L2 <= 1e-3 and the
+    converged-image RMSE are the stated radiance criteria; with the shared numeric rules the
+    images are in fact equal bit for bit."""
+    sc = scenes.cornell_box(256, 256)
+    seeds = scenes.frame_seeds(16, seed=1)
+    want = oracle.render_frames(oracle.Oracle(sc).build(), sc.params, seeds)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(sc.params)
+    core.set_dirty()
+    core.render_frames(seeds)
+    got = core.readback(wire.IMAGE_CONVERGED)
+    rel = H.relative_l2(got, want)
+    print(f"\nconfig 1: max per-pixel relative L2 {rel.max():.3e}, RMSE {_rmse(got, want):.3e}, mean radiance {want[..., :3].mean():.4f}")
+    assert rel.max() <= 1e-3
+    assert _rmse(got, want) <= 1e-4
+    H.assert_bits_equal(got, want, "Cornell 256x256x16")
+
+
+def test_config2_cornell_1080p_1024spp_properties(core, oracle):
+    """1920 x 1080, 1024 frames, MIS + ShadowMap pass with light radius 0.1: too long for the CPU
+    checker, so (a) a 120 x 68 crop-free miniature of the same setup is compared with it and
+    (b) the full run is checked through properties that do not depend on size: the accumulated
+    alpha has a closed form, two half runs joined through rt_upload_converged give the same
+    bits as one run, and every pixel is finite and within the range single frames span."""
+    def setup(w, h):
+        sc = scenes.cornell_box(w, h)
+        p = sc.params.copy()
+        p.flags |= wire.FLAG_MATTE_MASK                      # turns the ShadowMap pass on (RayTracing.cs:172-187)
+        p.lightParameter[3] = 0.1
+        p.shadowParameter[3] = 1.0
+        return sc, p
+
+    sc, p = setup(120, 68)
+    seeds = scenes.frame_seeds(6, seed=1)
+    want = oracle.render_frames(oracle.Oracle(sc).build(), p, seeds, use_shadow=True)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(p)
+    core.set_dirty()
+    core.render_frames(seeds)
+    assert H.relative_l2(core.readback(wire.IMAGE_CONVERGED), want).max() <= 1e-3
+
+    sc, p = setup(1920, 1080)
+    seeds = scenes.frame_seeds(1024, seed=1)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(p)
+    core.set_dirty()
+    core.render_frames(seeds)
+    ms = core.stats()["renderMs"]
+    full = core.readback(wire.IMAGE_CONVERGED)
+    assert core.sample_count == 1024 and np.isfinite(full).all()
+    # alpha: a_n = a*a + alpha*(1-a), a = 1/(n+1), in float32 (AddShader.shader:50-57)
+    alpha = np.float32(0)
+    for n in range(1024):
+        a = np.float32(1) / (np.float32(n) + np.float32(1))
+        alpha = a * a + alpha * (np.float32(1) - a)
+    H.assert_bits_equal(full[..., 3], np.full(full.shape[:2], alpha, np.float32), "accumulated alpha")
+    core.set_dirty()
+    core.render_frames(seeds[:512])
+    half = core.readback(wire.IMAGE_CONVERGED)
+    core.set_dirty()
+    core.upload_converged(half, 512)
+    core.render_frames(seeds[512:])
+    H.assert_bits_equal(core.readback(wire.IMAGE_CONVERGED), full, "512 + 512 frames vs 1024")
+    assert full[..., :3].min() >= 0 and full[..., :3].mean() > 0.05
+    print(f"\nconfig 2: 1024 frames of 1080p Cornell + ShadowMap pass in {ms:.0f} ms ({ms / 1024:.2f} ms per frame)")
+
+
+def test_config3_pbr_grid_against_checker_and_full_size(core, oracle):
+    """PBR sphere grid (metallic / smoothness / transparent / IOR / clear-coat rows) under the
+    procedural HDRI: a miniature against the checker, then 1080p x 256 frames for finiteness
+    and determinism (two runs, same bits)."""
+    sc = scenes.pbr_sphere_grid(96, 54, sphere_segments=12)
+    seeds = scenes.frame_seeds(4, seed=3)
+    want = oracle.render_frames(oracle.Oracle(sc).build(), sc.params, seeds)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(sc.params)
+    core.set_dirty()
+    core.render_frames(seeds)
+    got = core.readback(wire.IMAGE_CONVERGED)
+    assert H.relative_l2(got, want).max() <= 1e-3 and _rmse(got, want) <= 1e-4
+
+    sc = scenes.pbr_sphere_grid(1920, 1080)
+    seeds = scenes.frame_seeds(256, seed=1)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(sc.params)
+    images = []
+    for _ in range(2):
+        core.set_dirty()
+        core.render_frames(seeds)
+        images.append(core.readback(wire.IMAGE_CONVERGED))
+    ms = core.stats()["renderMs"]
+    assert np.isfinite(images[0]).all() and images[0][..., :3].mean() > 0.01
+    H.assert_bits_equal(images[0], images[1], "two runs of the same 256 frames")
+    print(f"\nconfig 3: {sc.n_triangles} triangles, 256 frames of 1080p in {ms:.0f} ms ({ms / 256:.2f} ms per frame)")
+
+
+def test_config4_car_4k_eight_tile_sets_make_the_whole_frame(core):
+    """3840 x 2160 car scene with depth of field and the ShadowMap pass, cut into 64 x 64 tiles for
+    8 ranks: every rank's accumulated tiles, placed by its pixel map, must reproduce the undivided
+    frame bit for bit (what the RCCL gather assembles on rank 0)."""
+    sc = scenes.car_standin(3840, 2160)
+    seeds = scenes.frame_seeds(2, seed=1)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(sc.params)
+    core.set_dirty()
+    core.render_frames(seeds)
+    whole = core.readback(wire.IMAGE_CONVERGED)
+    covered = np.zeros(whole.shape[0] * whole.shape[1], bool)
+    for rank in range(8):
+        p = sc.params.copy()
+        p.tileRank, p.tileCount, p.tileSize = rank, 8, 64
+        core.set_params(p)
+        core.set_dirty()
+        core.render_frames(seeds)
+        part = core.readback(wire.IMAGE_CONVERGED).reshape(-1, 4)
+        pm = core.local_pixel_map()
+        pm = pm[pm != 0xFFFFFFFF]
+        assert not covered[pm].any()
+        covered[pm] = True
+        assert part[pm].tobytes() == whole.reshape(-1, 4)[pm].tobytes(), f"rank {rank}"
+    assert covered.all()
