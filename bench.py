@@ -205,15 +205,22 @@ def main():
             achieved = per_launch / (ms / n * 1e-3) / 1e9
             m = measured.get(kernel, {})
             same = m.get("workload") == workload_name and m.get("n_gpus") == world
+            traffic = m.get("hbm_bytes_per_launch") if same else None
+            counters = None
+            if same:   # from the committed rocprofv3 --pmc passes of this same command (profiles/)
+                counters = {k: m.get(k) for k in ("l2_hit_rate", "lane_utilisation", "waves_per_simd", "valu_busy")}
+                counters["hbm_gbps"] = round(traffic / (ms / n * 1e-3) / 1e9, 1)
+                counters["hbm_frac_of_peak"] = round(counters["hbm_gbps"] / HBM_PEAK_GBS, 4)
             return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": m.get("hbm_bytes_per_launch") if same else None,
+                    "traffic": traffic, "counters": counters,
                     "kernel": kernel, "launches": int(n), "avg_launch_ms": round(ms / n, 4),
                     "algorithmic_bytes_per_launch": int(per_launch),
                     "note": "achieved = algorithmic bytes (every box, leaf and triangle record a ray needs, counted by the "
-                            "instrumented kernel) / launch time; traffic = HBM bytes per launch from the committed PMC "
-                            "pass. Nearly all node reads are served by L1/L2/Infinity Cache, hence traffic << algorithmic "
-                            "bytes and frac is not capped at 1"}, ms
+                            "instrumented kernel) / launch time; traffic = memory-side bytes per launch (FETCH_SIZE x 2 + "
+                            "WRITE_SIZE) from the committed PMC passes. The tree is re-read from L2 / Infinity Cache, hence "
+                            "traffic << algorithmic bytes and frac is not capped at 1; the kernel's binding resource is "
+                            "vector-instruction issue (counters.valu_busy x counters.lane_utilisation)"}, ms
 
         r_path, ms_path = roof("k_extend", "k_traverse<QueueSrc>", path_ray_bytes(local_path))
         r_shadow, ms_shadow = roof("k_shadow_rays", "k_traverse<ShadowSrc>", shadow_ray_bytes(local_shadow))
