@@ -28,6 +28,7 @@ class Transform:
     position: tuple = (0.0, 0.0, 0.0)
     rotation: tuple = scenes.IDENTITY_Q
     localScale: tuple = (1.0, 1.0, 1.0)
+    matrix: Optional[np.ndarray] = None           # localToWorldMatrix of a transform with parents (overrides the three above)
 
     @property
     def forward(self):
@@ -109,7 +110,7 @@ class BVH:
         b = scenes.SceneBuilder()
         for mr in mrs:
             b.add(mr.sharedMesh, mr.sharedMaterial, mr.transform.position, mr.transform.rotation, mr.transform.localScale,
-                  cast_shadow=mr.shadowCastingOn, receive_shadow=mr.receiveShadows)
+                  cast_shadow=mr.shadowCastingOn, receive_shadow=mr.receiveShadows, matrix=mr.transform.matrix)
         materials = list(b.mats)
         self.mesh = (np.concatenate(b.v), np.concatenate(b.i), np.concatenate(b.mi), np.concatenate(b.sh))
         return self.mesh, materials
@@ -146,7 +147,8 @@ class LightImportanceSampling:
         self.areaLightParent = areaLightParent or []
         self.discLightParent = discLightParent or []
 
-    def Init(self, core: RtCore):
+    def Lights(self):
+        """(sphere, area, disc) light arrays in wire layout."""
         sph = [scenes.sphere_light(l.transform.position, l.colliderRadius, l.transform.localScale[0])
                for l in self.sphereLightParent if l.active]
         area = [scenes.area_light(l.transform.position, l.transform.rotation, l.colliderSize[:2], l.transform.localScale)
@@ -159,7 +161,10 @@ class LightImportanceSampling:
                 d["normal"] = (-l.transform.forward).astype(np.float32)
                 d["radius"] = np.float32(l.colliderRadius) * np.float32(l.transform.localScale[0])
                 disc.append(d)
-        core.lights_upload(np.array(sph, wire.SPHERE_LIGHT), np.array(area, wire.AREA_LIGHT), np.array(disc, wire.DISC_LIGHT))
+        return np.array(sph, wire.SPHERE_LIGHT), np.array(area, wire.AREA_LIGHT), np.array(disc, wire.DISC_LIGHT)
+
+    def Init(self, core: RtCore):
+        core.lights_upload(*self.Lights())
 
 
 # ------------------------------------------------------------------ DepthOfField.cs
@@ -230,6 +235,11 @@ class RayTracing:
             raise ValueError(self.samplingType)
 
     def UpdateParameters(self):                  # :219-239 (+ the Set* calls of InitShader/InitLight/InitSampling)
+        self.params = self.BuildParameters()
+        self.core.set_params(self.params)
+
+    def BuildParameters(self):
+        """Every uniform the frame needs as one RtParams (draws the frame's three Random.value)."""
         flags = self.SamplingType[self.samplingType]
         if self.depthOfField.enabled:
             flags |= wire.FLAG_DEPTH_OF_FIELD
@@ -249,8 +259,7 @@ class RayTracing:
         p.lensRadius, p.focalLength = self.depthOfField.lensRadius, self.depthOfField.focalLength
         p.flags = flags
         p.tileRank, p.tileCount, p.tileSize = 0, 1, 64
-        self.params = p
-        self.core.set_params(p)
+        return p
 
     # RayTracing.cs:118-164
     def CustomRender(self):

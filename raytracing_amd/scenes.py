@@ -226,11 +226,18 @@ class SceneBuilder:
         self.offset = 0
 
     def add(self, mesh, material, position=(0, 0, 0), rotation=IDENTITY_Q, scale=(1, 1, 1),
-            cast_shadow=True, receive_shadow=True):
-        s = np.asarray(scale, np.float64)
-        pos = quat_rotate(rotation, mesh.positions.astype(np.float64) * s) + np.asarray(position, np.float64)
-        nrm = quat_rotate(rotation, mesh.normals.astype(np.float64) * s)      # TransformVector: scaled
-        tan = quat_rotate(rotation, mesh.tangents.astype(np.float64) * s)
+            cast_shadow=True, receive_shadow=True, matrix=None):
+        """matrix: a 4x4 localToWorld of a transform hierarchy, used instead of position / rotation / scale."""
+        if matrix is not None:
+            m = np.asarray(matrix, np.float64)
+            pos = mesh.positions.astype(np.float64) @ m[:3, :3].T + m[:3, 3]   # TransformPoint
+            nrm = mesh.normals.astype(np.float64) @ m[:3, :3].T                # TransformVector: scaled, not renormalised
+            tan = mesh.tangents.astype(np.float64) @ m[:3, :3].T
+        else:
+            s = np.asarray(scale, np.float64)
+            pos = quat_rotate(rotation, mesh.positions.astype(np.float64) * s) + np.asarray(position, np.float64)
+            nrm = quat_rotate(rotation, mesh.normals.astype(np.float64) * s)      # TransformVector: scaled
+            tan = quat_rotate(rotation, mesh.tangents.astype(np.float64) * s)
         v = np.zeros(len(pos), wire.MESH_VERTEX)
         v["position"], v["normal"], v["tangent"], v["uv"] = pos.astype(F32), nrm.astype(F32), tan.astype(F32), mesh.uvs
         self.v.append(v)

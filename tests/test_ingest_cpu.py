@@ -1,0 +1,340 @@
+"""Scene ingest (the step in front of the hot path): binary FBX, Unity YAML, PNG.
+Synthetic files are written by the tests; where the reference checkout is present
+(/root/reference, not on the GPU box) its own meshes and scenes are read as well."""
+import os
+
+import numpy as np
+import pytest
+
+from raytracing_amd import scenes, wire
+from raytracing_amd.ingest import fbx, png, unity
+
+REF = "/root/reference"
+needs_reference = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "Assets")), reason="reference checkout not present")
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ------------------------------------------------------------------ FBX
+@pytest.mark.parametrize("version,compress", [(7400, True), (7500, True), (7500, False)])
+def test_fbx_polygons_become_mirrored_fans(version, compress):
+    ctrl = [[0, 0, 0], [2, 0, 0], [2, 1, 0], [1, 2, 0], [0, 1, 0]]
+    normals = [[0, 0, 1]] * 5 + [[0, 1, 0]] * 3
+    data = fbx.write_minimal([("shape", ctrl, [[0, 1, 2, 3, 4], [0, 4, 1]], normals)], version=version, compress=compress)
+    (m,) = fbx.load_meshes(data)
+    assert m.name == "shape"
+    assert len(m.triangles) == 3 + 1                                  # pentagon fan + triangle
+    assert m.positions[:, 0].min() == -2 and m.positions[:, 0].max() == 0   # x mirrored
+    # the pentagon faces +z in the right-handed file; mirrored, Unity's clockwise front faces still face +z
+    tri = m.positions[m.triangles[:3]].astype(np.float64)
+    gn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    assert (gn[:, 2] > 0).all()
+    assert np.allclose(m.normals[m.triangles[0]], [[0, 0, 1]] * 3)
+    # corners 0, 1, 4 appear in both polygons with different normals -> split, the rest welded
+    assert len(m.positions) == 5 + 3
+
+
+def test_fbx_units_and_global_scale():
+    data = fbx.write_minimal([("t", [[0, 0, 0], [100, 0, 0], [0, 100, 0]], [[0, 1, 2]], None)], unit_scale=2.54)
+    assert fbx.load_meshes(data, global_scale=0.5)[0].positions[:, 0].min() == -50
+    assert np.isclose(fbx.load_meshes(data, global_scale=1.0, use_file_scale=True)[0].positions[:, 0].min(), -2.54)
+    with pytest.raises(ValueError):
+        fbx.parse(b"not an fbx file at all........")
+
+
+@needs_reference
+@pytest.mark.parametrize("name,tris", [("sphere16", 480), ("sphere32", 1984), ("sphere64", 8064), ("roundBox", 668), ("teapot", 4032)])
+def test_reference_meshes(name, tris):
+    (m,) = fbx.load_meshes(open(f"{REF}/Assets/Meshes/{name}.fbx", "rb").read())
+    assert len(m.triangles) == tris and m.triangles.max() < len(m.positions)
+    assert np.allclose(np.linalg.norm(m.normals, axis=1), 1, atol=1e-4)
+    if name.startswith("sphere"):
+        assert np.allclose(np.linalg.norm(m.positions, axis=1), 1, atol=1e-4)          # radius 1
+        assert (np.einsum("ij,ij->i", m.positions, m.normals) > 0.99).all()            # normals outward
+        tri = m.positions[m.triangles].astype(np.float64)
+        gn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+        assert (np.einsum("ij,ij->i", gn, tri.mean(1)) > 0).all()                      # front faces outward
+        # closed: every undirected edge of the position-welded surface is shared by exactly two triangles
+        _, pid = np.unique(m.positions.round(5), axis=0, return_inverse=True)
+        t = pid.reshape(-1)[m.triangles]
+        e = np.sort(np.concatenate([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]]), 1)
+        e = e[e[:, 0] != e[:, 1]]
+        assert (np.unique(e, axis=0, return_counts=True)[1] == 2).all()
+
+
+# ------------------------------------------------------------------ Unity YAML
+SCENE = """%YAML 1.1
+%TAG !u! tag:unity3d.com,2011:
+--- !u!1 &100
+GameObject:
+  m_Component:
+  - component: {fileID: 101}
+  m_Name: Meshes
+  m_IsActive: 1
+--- !u!4 &101
+Transform:
+  m_GameObject: {fileID: 100}
+  m_LocalRotation: {x: 0, y: 0.7071068, z: 0, w: 0.7071068}
+  m_LocalPosition: {x: 1, y: 2, z: 3}
+  m_LocalScale: {x: 2, y: 2, z: 2}
+  m_Children:
+  - {fileID: 111}
+  - {fileID: 121}
+  m_Father: {fileID: 0}
+--- !u!1 &110
+GameObject:
+  m_Component:
+  - component: {fileID: 111}
+  m_Name: Floor
+  m_IsActive: 1
+--- !u!4 &111
+Transform:
+  m_GameObject: {fileID: 110}
+  m_LocalRotation: {x: 0.7071068, y: 0, z: 0, w: 0.7071068}
+  m_LocalPosition: {x: 0, y: 0, z: 5}
+  m_LocalScale: {x: 3, y: 4, z: 1}
+  m_Children: []
+  m_Father: {fileID: 101}
+--- !u!33 &112
+MeshFilter:
+  m_GameObject: {fileID: 110}
+  m_Mesh: {fileID: 10210, guid: 0000000000000000e000000000000000, type: 0}
+--- !u!23 &113
+MeshRenderer:
+  m_GameObject: {fileID: 110}
+  m_Enabled: 1
+  m_CastShadows: 0
+  m_ReceiveShadows: 1
+  m_Materials:
+  - {fileID: 2100000, guid: aaaaaaaaaaaaaaaaaaaaaaaaaaaaaaa1, type: 2}
+--- !u!1 &120
+GameObject:
+  m_Component:
+  - component: {fileID: 121}
+  m_Name: Hidden
+  m_IsActive: 0
+--- !u!4 &121
+Transform:
+  m_GameObject: {fileID: 120}
+  m_LocalRotation: {x: 0, y: 0, z: 0, w: 1}
+  m_LocalPosition: {x: 0, y: 0, z: 0}
+  m_LocalScale: {x: 1, y: 1, z: 1}
+  m_Children: []
+  m_Father: {fileID: 101}
+--- !u!33 &122
+MeshFilter:
+  m_GameObject: {fileID: 120}
+  m_Mesh: {fileID: 10202, guid: 0000000000000000e000000000000000, type: 0}
+--- !u!23 &123
+MeshRenderer:
+  m_GameObject: {fileID: 120}
+  m_Enabled: 1
+  m_CastShadows: 1
+  m_ReceiveShadows: 1
+  m_Materials:
+  - {fileID: 2100000, guid: aaaaaaaaaaaaaaaaaaaaaaaaaaaaaaa2, type: 2}
+--- !u!1 &200
+GameObject:
+  m_Component:
+  - component: {fileID: 201}
+  m_Name: AreaLights
+  m_IsActive: 1
+--- !u!4 &201
+Transform:
+  m_GameObject: {fileID: 200}
+  m_LocalRotation: {x: 0, y: 0, z: 0, w: 1}
+  m_LocalPosition: {x: 0, y: 10, z: 0}
+  m_LocalScale: {x: 1, y: 1, z: 1}
+  m_Children:
+  - {fileID: 211}
+  m_Father: {fileID: 0}
+--- !u!1 &210
+GameObject:
+  m_Component:
+  - component: {fileID: 211}
+  m_Name: Light
+  m_IsActive: 1
+--- !u!4 &211
+Transform:
+  m_GameObject: {fileID: 210}
+  m_LocalRotation: {x: -0.7071068, y: 0, z: 0, w: 0.7071068}
+  m_LocalPosition: {x: 0, y: 4, z: 0}
+  m_LocalScale: {x: 6, y: 5, z: 1}
+  m_Children: []
+  m_Father: {fileID: 201}
+--- !u!65 &212
+BoxCollider:
+  m_GameObject: {fileID: 210}
+  m_Size: {x: 1, y: 2, z: 0}
+--- !u!1 &300
+GameObject:
+  m_Component:
+  - component: {fileID: 301}
+  m_Name: Main Camera
+  m_IsActive: 1
+--- !u!4 &301
+Transform:
+  m_GameObject: {fileID: 300}
+  m_LocalRotation: {x: 0, y: 0, z: 0, w: 1}
+  m_LocalPosition: {x: 0, y: 5, z: -20}
+  m_LocalScale: {x: 1, y: 1, z: 1}
+  m_Children: []
+  m_Father: {fileID: 0}
+--- !u!20 &302
+Camera:
+  m_GameObject: {fileID: 300}
+  near clip plane: 0.3
+  far clip plane: 500
+  field of view: 42
+--- !u!114 &303
+MonoBehaviour:
+  m_GameObject: {fileID: 300}
+  m_Script: {fileID: 11500000, guid: bbbbbbbbbbbbbbbbbbbbbbbbbbbbbbb1, type: 3}
+  skyboxIntensityMulitiply: 1.5
+  shadowColor: {r: 0.1, g: 0.2, b: 0.3, a: 1}
+  lightRadius: 0.25
+  shadowIntensity: 0.5
+  aliasing: 1
+  bvh: {fileID: 304}
+  useBVH: 1
+  samplingType: 3
+  lightImportanceSampling: {fileID: 305}
+  matteMaskGO: {fileID: 0}
+--- !u!114 &304
+MonoBehaviour:
+  m_GameObject: {fileID: 300}
+  m_Script: {fileID: 11500000, guid: bbbbbbbbbbbbbbbbbbbbbbbbbbbbbbb2, type: 3}
+  meshParent: {fileID: 101}
+--- !u!114 &305
+MonoBehaviour:
+  m_GameObject: {fileID: 300}
+  m_Script: {fileID: 11500000, guid: bbbbbbbbbbbbbbbbbbbbbbbbbbbbbbb3, type: 3}
+  sphereLightParent: {fileID: 0}
+  areaLightParent: {fileID: 201}
+  discLightParent: {fileID: 0}
+"""
+
+MAT = """%YAML 1.1
+%TAG !u! tag:unity3d.com,2011:
+--- !u!21 &2100000
+Material:
+  m_Name: Glow
+  m_ValidKeywords:
+  - _EMISSION
+  m_SavedProperties:
+    m_Floats:
+    - _Glossiness: 0.8
+    - _Metallic: 0
+    - _Mode: 3
+    m_Colors:
+    - _Color: {r: 0.5, g: 0.25, b: 1, a: 0.4}
+    - _EmissionColor: {r: 2, g: 3, b: 4, a: 1}
+"""
+
+
+@pytest.fixture
+def project(tmp_path):
+    a = tmp_path / "Assets"
+    (a / "Scripts").mkdir(parents=True)
+    for name, g in (("RayTracing", "1"), ("BVH", "2"), ("LightImportanceSampling", "3")):
+        (a / "Scripts" / f"{name}.cs.meta").write_text(f"fileFormatVersion: 2\nguid: {'b' * 31}{g}\n")
+    (a / "Glow.mat").write_text(MAT)
+    (a / "Glow.mat.meta").write_text(f"fileFormatVersion: 2\nguid: {'a' * 31}1\n")
+    (a / "scene.unity").write_text(SCENE)
+    return tmp_path
+
+
+def test_unity_scene_graph_materials_lights_camera(project):
+    ls = unity.load_scene(str(project / "Assets" / "scene.unity"), str(project), 64, 48)
+    rt = ls.rayTracing
+    assert rt.samplingType == "BSDFImportance" and rt.lightRadius == 0.25 and rt.shadowIntensity == 0.5
+    assert rt.shadowColor == (0.1, 0.2, 0.3) and rt.skyboxIntensityMulitiply == 1.5
+    assert rt.cam.fieldOfView == 42 and rt.cam.farClipPlane == 500 and tuple(rt.cam.transform.position) == (0, 5, -20)
+    floor, hidden = rt.bvh.meshParent
+    assert floor.activeInHierarchy and not hidden.activeInHierarchy and not floor.shadowCastingOn
+    # localToWorld = parent TRS * child TRS: the quad corner (0.5, 0.5, 0) -> scale (3,4,1) -> rotate 90 deg about x
+    # -> (1.5, 0, 2) -> + (0,0,5) -> parent: scale 2 -> (3, 0, 14) -> rotate 90 deg about y -> (14, 0, -3) -> + (1,2,3)
+    corner = floor.transform.matrix @ np.array([0.5, 0.5, 0.0, 1.0])
+    assert np.allclose(corner[:3], [15, 2, 0], atol=1e-5)
+    m = floor.sharedMaterial.MaterialData()
+    assert m["materialType"] == 2 and np.allclose(m["emissionColor"], [2, 3, 4])          # emission wins (BVH.cs:38-76)
+    assert np.isclose(m["transparent"], 0.4) and np.allclose(m["albedo"], scenes.srgb_to_linear([0.5, 0.25, 1.0]))
+    (mesh, materials) = rt.bvh.InitMesh()
+    assert len(mesh[2]) == 2 and len(materials) == 1                                       # only the active quad
+    sph, area, disc = rt.lightImportanceSampling.Lights()
+    assert len(sph) == 0 and len(disc) == 0 and len(area) == 1
+    assert np.allclose(area[0]["position"], [0, 14, 0]) and np.allclose(area[0]["normal"], [0, -1, 0], atol=1e-6)
+    assert np.allclose(area[0]["size"], [6, 10])                                           # collider size * local scale
+    p = rt.BuildParameters()
+    assert p.flags & 0xF == wire.SAMPLING_BSDF and p.width == 64
+
+
+# ------------------------------------------------------------------ PNG
+def test_png_round_trip(tmp_path):
+    rs = np.random.Generator(np.random.PCG64(1))
+    for c in (3, 4):
+        img = rs.integers(0, 256, (37, 53, c), dtype=np.uint8)
+        png.write_png(str(tmp_path / "a.png"), img)
+        assert np.array_equal(png.read_png(str(tmp_path / "a.png")), img)
+    assert png.linear_to_srgb8(np.array([0.0, 0.0031308, 0.2159, 1.0, 7.0])).tolist() == [0, 10, 128, 255, 255]
+
+
+# ------------------------------------------------------------------ the reference's own scene
+@needs_reference
+def test_chapter6_3_facts_and_committed_fixture():
+    ref = png.read_png(f"{REF}/Assets/Outputs/CornellBox.png")                 # exercises the Paeth / sub / up filters
+    assert ref.shape == (757, 1211, 3)
+    ls = unity.load_scene(f"{REF}/Assets/Scenes/Chapter6_3.unity", REF, 1211, 757)
+    rt = ls.rayTracing
+    assert tuple(np.round(rt.cam.transform.position, 4)) == (0.0, 5.8, -21.2) and rt.cam.fieldOfView == 50
+    assert rt.samplingType == "MultipleImportance" and rt.lightRadius == 0.1
+    sph, area, disc = rt.lightImportanceSampling.Lights()
+    assert (len(sph), len(area), len(disc)) == (0, 1, 0) and np.allclose(area[0]["position"], [0, 14.97, 0])
+    assert np.allclose(area[0]["size"], [6, 6], atol=1e-5)
+    (v, i, mi, sh), mats = rt.bvh.InitMesh()
+    z = np.load(os.path.join(GOLDEN, "unity_chapter6_3_scene.npz"))
+    assert v.tobytes() == z["vertices"].tobytes() and np.array_equal(i, z["indices"]) and np.array_equal(mi, z["material_index"])
+    k = 16
+    blocks = ref[:757 // k * k, :1211 // k * k].astype(np.float64).reshape(757 // k, k, 1211 // k, k, 3).mean((1, 3))
+    assert np.allclose(blocks, np.load(os.path.join(GOLDEN, "reference_cornellbox_blocks.npy")), atol=1e-3)
+
+
+@needs_reference
+def test_every_bvh_scene_of_the_reference_loads():
+    loaded = 0
+    for fn in sorted(os.listdir(f"{REF}/Assets/Scenes")):
+        if not fn.endswith(".unity"):
+            continue
+        try:
+            ls = unity.load_scene(f"{REF}/Assets/Scenes/{fn}", REF, 64, 64)
+        except ValueError:
+            continue                                  # no RayTracing component
+        if not ls.rayTracing.useBVH or not ls.rayTracing.bvh.meshParent:
+            continue
+        (v, i, mi, sh), mats = ls.rayTracing.bvh.InitMesh()
+        assert len(i) == 3 * len(mi) and i.max() < len(v) and np.isfinite(v["position"]).all(), fn
+        loaded += 1
+    assert loaded >= 5
+
+
+def test_reference_image_against_the_cpu_checker(oracle):
+    """The committed arrays of Assets/Scenes/Chapter6_3.unity, rendered by the CPU checker at 1/8 of the
+    published image's size, against the published image itself (Assets/Outputs/CornellBox.png reduced to
+    block means).  Sky, sample count and tone of the published image are not known, so the bound is loose;
+    it catches a wrong camera, a mirrored mesh, wrong materials or a wrong light."""
+    z = np.load(os.path.join(GOLDEN, "unity_chapter6_3_scene.npz"))
+    p = wire.RtParams.from_buffer_copy(z["params"].tobytes())
+    p.width, p.height = 1211 // 8, 757 // 8
+    p.cameraInverseProjection[:] = scenes.inverse_projection(50.0, p.width / p.height).tolist()
+    sc = scenes.Scene("chapter6_3", z["vertices"], z["indices"], z["material_index"], z["shadow_index"], z["materials"],
+                      z["sphere_lights"], z["area_lights"], z["disc_lights"], scenes.procedural_skybox(32), p)
+    img = oracle.render_frames(oracle.Oracle(sc).build(), p, scenes.frame_seeds(12, 1))
+    got = png.linear_to_srgb8(img[::-1, :, :3]).astype(np.float64)
+    want = np.load(os.path.join(GOLDEN, "reference_cornellbox_blocks.npy")).astype(np.float64)      # 16 x 16 blocks of 1211 x 757
+    g = got[:want.shape[0] * 2, :want.shape[1] * 2].reshape(want.shape[0], 2, want.shape[1], 2, 3).mean((1, 3))
+
+    def coarse(x, k=4):                              # 64 x 64 pixel blocks of the published image: averages the noise out
+        return x[:x.shape[0] // k * k, :x.shape[1] // k * k].reshape(x.shape[0] // k, k, x.shape[1] // k, k, 3).mean((1, 3))
+
+    d = np.abs(coarse(g) - coarse(want)).max(-1)
+    print(f"\nchecker vs published image: median block difference {np.median(d):.1f}/255, {100 * (d <= 10).mean():.0f}% within 10")
+    assert np.median(d) <= 6 and (d <= 10).mean() >= 0.8
