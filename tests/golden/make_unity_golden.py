@@ -7,6 +7,9 @@
                                raytracing_amd.ingest (positions, normals, indices, materials, one area light, camera)
   reference_cornellbox_blocks.npy   16 x 16 block means (sRGB, 0..255) of Assets/Outputs/CornellBox.png, the
                                image the reference's author rendered from that scene
+  unity_chapter6_{4,2}_scene.npz, reference_{mis,lightsampling}_blocks.npy
+                               the same for Assets/Scenes/Chapter6_4.unity (20 sphere lights over five plates, MIS.png)
+                               and Chapter6_2.unity (LightSampling.png)
 
 Run where the reference checkout is available:  python tests/golden/make_unity_golden.py /root/reference
 """
@@ -21,16 +24,33 @@ from raytracing_amd import wire  # noqa: E402
 from raytracing_amd.ingest import png, unity  # noqa: E402
 
 root = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
-ref = png.read_png(os.path.join(root, "Assets/Outputs/CornellBox.png")).astype(np.float64)
-h, w = ref.shape[:2]
-ls = unity.load_scene(os.path.join(root, "Assets/Scenes/Chapter6_3.unity"), root, w, h)
-rt = ls.rayTracing
-(v, i, mi, sh), mats = rt.bvh.InitMesh()
-sph, area, disc = rt.lightImportanceSampling.Lights()
-np.savez_compressed(os.path.join(HERE, "unity_chapter6_3_scene.npz"), vertices=v, indices=i, material_index=mi, shadow_index=sh,
-                    materials=np.array([m.MaterialData() for m in mats], wire.MATERIAL), sphere_lights=sph, area_lights=area,
-                    disc_lights=disc, params=np.frombuffer(bytes(rt.BuildParameters()), np.uint8))
-k = 16
-blocks = ref[:h // k * k, :w // k * k].reshape(h // k, k, w // k, k, 3).mean((1, 3)).astype(np.float32)
-np.save(os.path.join(HERE, "reference_cornellbox_blocks.npy"), blocks)
-print(f"{len(mi)} triangles, {len(mats)} materials, image {w}x{h} -> {blocks.shape} blocks")
+K = 16
+
+
+def blocks_of(name):
+    ref = png.read_png(os.path.join(root, "Assets/Outputs", name)).astype(np.float64)
+    h, w = ref.shape[:2]
+    return ref[:h // K * K, :w // K * K].reshape(h // K, K, w // K, K, 3).mean((1, 3)).astype(np.float32), w, h
+
+
+def export(scene, out, w, h):
+    ls = unity.load_scene(os.path.join(root, "Assets/Scenes", scene), root, w, h)
+    rt = ls.rayTracing
+    (v, i, mi, sh), mats = rt.bvh.InitMesh()
+    sph, area, disc = rt.lightImportanceSampling.Lights()
+    np.savez_compressed(os.path.join(HERE, out), vertices=v, indices=i, material_index=mi, shadow_index=sh,
+                        materials=np.array([m.MaterialData() for m in mats], wire.MATERIAL), sphere_lights=sph, area_lights=area,
+                        disc_lights=disc, params=np.frombuffer(bytes(rt.BuildParameters()), np.uint8))
+    print(f"{scene}: {len(mi)} triangles, {len(mats)} materials, {len(sph)}/{len(area)}/{len(disc)} lights -> {out}")
+
+
+b, w, h = blocks_of("CornellBox.png")
+np.save(os.path.join(HERE, "reference_cornellbox_blocks.npy"), b)
+export("Chapter6_3.unity", "unity_chapter6_3_scene.npz", w, h)
+# Chapter6_4: five plates of rising smoothness under four sphere lights each (MIS.png);
+# Chapter6_2: the box lit by light sampling only
+# (CosineSampling.png was rendered from a scene state that is not in the checkout: its light is smaller.)
+for name, scene in (("MIS", "Chapter6_4"), ("LightSampling", "Chapter6_2")):
+    b, w, h = blocks_of(name + ".png")
+    np.save(os.path.join(HERE, f"reference_{name.lower()}_blocks.npy"), b)
+    export(scene + ".unity", f"unity_{scene.lower()}_scene.npz", w, h)
