@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=64)
     ap.add_argument("--detail", type=float, default=1.0)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo stages the two exchanges through host "
+                                                      "memory, for rehearsing the multi-rank path on one GPU")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -113,12 +116,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    comm_device = device if args.backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     def barrier():
         if dist is not None:
@@ -127,7 +136,7 @@ def main():
     # ---- scene: generated on rank 0, broadcast over RCCL, built on every GPU
     sc = make_scene(args) if rank == 0 else None
     if world > 1:
-        sc = rtdist.broadcast_scene(sc, device)
+        sc = rtdist.broadcast_scene(sc, comm_device)
     core = native.RtCore(local_rank)
     core.upload(sc)
     core.bvh_build()
@@ -136,14 +145,19 @@ def main():
     params.tileRank, params.tileCount, params.tileSize = rank, world, 64
     core.set_params(params)
     seeds = scenes.frame_seeds(args.spp, seed=1)
-    gatherer = rtdist.TileGatherer(args.width, args.height, 64, device)
+    gatherer = rtdist.TileGatherer(args.width, args.height, 64, comm_device)
+    staging = None if comm_device == device else torch.zeros(gatherer.n_local * 4, dtype=torch.float32, device=device)
     assert gatherer.n_local == core.local_pixel_count
     # the library's slot->pixel mapping and the host-side statement of it must agree
     assert np.array_equal(rtdist.tile_pixel_map(args.width, args.height, 64, rank, world).astype(np.uint32), core.local_pixel_map())
 
     def gather_frame():
         """Accumulated tiles -> rank 0, once per finished image (device to device)."""
-        core.readback_local_device(wire.IMAGE_CONVERGED, gatherer.local_buffer().data_ptr())
+        if staging is None:
+            core.readback_local_device(wire.IMAGE_CONVERGED, gatherer.local_buffer().data_ptr())
+        else:
+            core.readback_local_device(wire.IMAGE_CONVERGED, staging.data_ptr())
+            gatherer.local_buffer().copy_(staging)
         return gatherer.gather()
 
     def step():
@@ -157,7 +171,7 @@ def main():
     step()
     st = core.stats()
     core.enable_counters(False)
-    counts = torch.tensor([st[k] for k in COUNT_KEYS], dtype=torch.int64, device=device)
+    counts = torch.tensor([st[k] for k in COUNT_KEYS], dtype=torch.int64, device=comm_device)
     local_shadow = {k: int(st[sk]) for k, sk in zip(COUNT_KEYS, SHADOW_KEYS)}
     local_path = {k: int(st[k]) - local_shadow[k] for k in COUNT_KEYS}
     if world > 1:
@@ -181,7 +195,7 @@ def main():
     elapsed = time.perf_counter() - t0
     core.enable_kernel_timing(False)
     if world > 1:
-        et = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        et = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         elapsed = float(et.item())
 
