@@ -493,6 +493,7 @@ int rt_set_option(RtContext *ctx, int option, int value)
     case RT_OPT_PACKET_SHADOW: ctx->optPacketShadow = value != 0; return RT_OK;
     case RT_OPT_PACKET_PRIMARY: ctx->optPacketPrimary = value != 0; return RT_OK;
     case RT_OPT_PACKET_TRACE: ctx->optPacketTrace = value != 0; return RT_OK;
+    case RT_OPT_MATERIAL_SORT: ctx->optMaterialSort = value != 0; return RT_OK;
     case RT_OPT_BATCH_FRAMES:
         if (value < 0 || value > 64) return rt_fail(ctx, RT_E_INVALID, "RT_OPT_BATCH_FRAMES must be 0..64");
         ctx->optBatchFrames = (uint32_t)value;

@@ -232,6 +232,11 @@ __device__ __forceinline__ void load_hit(const RtSceneView &sv, const RtHitRec &
 // An emissive hit leaves ray and energy untouched in the reference, so the same
 // ray hits the same emitter on every remaining bounce; those identical
 // iterations are added here in one go (same float additions, no re-tracing).
+// SORT: the block first groups the 2048 paths of its tile by what their shading will do (miss,
+// emitter, matte mask, opaque, glass, clear coat) with a counting sort in LDS, so that a wave
+// mostly runs one of those branches instead of all of them.  Paths are independent and carry
+// their own random stream, so the order they are shaded in changes no value.
+template <bool SORT>
 __global__ __launch_bounds__(Q_THREADS) void k_shade(RtSceneView sv, RtTileMap tm, RtParams P, int bounce, const uint32_t *__restrict__ queueIn,
                                                 const uint32_t *__restrict__ countIn, uint32_t *__restrict__ queueOut,
                                                 uint32_t *__restrict__ countOut, float4 *__restrict__ po,
@@ -239,15 +244,49 @@ __global__ __launch_bounds__(Q_THREADS) void k_shade(RtSceneView sv, RtTileMap t
                                                 uint2 *__restrict__ rng, const RtHitRec *__restrict__ hitRec)
 {
     __shared__ uint32_t stage[Q_TILE];
+    __shared__ uint32_t order[SORT ? Q_TILE : 1];
+    __shared__ uint32_t bin[8];
     const uint32_t n = *countIn;
     if (blockIdx.x * Q_TILE >= n) return;
+    if (SORT) {
+        if (threadIdx.x < 8) bin[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t slots[Q_ITEMS], where[Q_ITEMS];
+#pragma unroll
+        for (int it = 0; it < Q_ITEMS; ++it) {
+            const uint32_t i = blockIdx.x * Q_TILE + it * Q_THREADS + threadIdx.x;
+            uint32_t key = 7u;                                   // past the end of the queue
+            slots[it] = RT_INVALID;
+            if (i < n) {
+                slots[it] = queueIn[i];
+                const uint32_t leaf = hitRec[slots[it]].leaf;
+                key = 0u;                                        // miss
+                if (leaf != RT_INVALID) {
+                    const uint32_t mi = __float_as_uint(((const float4 *)(sv.leafShade + leaf))[2].y);
+                    const uint32_t type = mi < sv.nMaterials ? sv.materials[mi].materialType : 0u;
+                    key = type == 2u ? 1u : type == 4u ? 2u : type == 1u ? 4u : type == 3u ? 5u : 3u;
+                }
+            }
+            where[it] = (key << 16) | atomicAdd(&bin[key], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (int k = 0; k < 8; ++k) { const uint32_t c = bin[k]; bin[k] = run; run += c; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < Q_ITEMS; ++it) order[bin[where[it] >> 16] + (where[it] & 0xFFFFu)] = slots[it];
+        __syncthreads();
+    }
 #pragma unroll 1
     for (int it = 0; it < Q_ITEMS; ++it) {
     const uint32_t i = blockIdx.x * Q_TILE + it * Q_THREADS + threadIdx.x;
     bool alive = false;
     uint32_t slot = 0;
-    if (i < n) {
-        slot = queueIn[i];
+    const uint32_t sortedSlot = SORT ? order[it * Q_THREADS + threadIdx.x] : 0u;
+    if (SORT ? sortedSlot != RT_INVALID : i < n) {
+        slot = SORT ? sortedSlot : queueIn[i];
         const float4 o4 = po[slot], d4 = pd[slot], e4 = pe[slot];
         float4 c4 = rt[slot];
         const RtHitRec h = hitRec[slot];
@@ -653,8 +692,12 @@ static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup
         else launch_traverse(ctx, sv, src, ctx->dQCount + CNT_FETCH + b, total, "k_extend");
         if (b == 0 && withShadowSetup) launch_sm_setup(ctx, sv, total, qin, ctx->dQCount);   // before shade moves the rays on
         rt_timer_begin(ctx, "k_shade");
-        hipLaunchKernelGGL(k_shade, grid, blk, 0, st, sv, ctx->tile, ctx->params, b, qin, ctx->dQCount + b, qout, ctx->dQCount + b + 1,
-                           ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
+        if (ctx->optMaterialSort)
+            hipLaunchKernelGGL(k_shade<true>, grid, blk, 0, st, sv, ctx->tile, ctx->params, b, qin, ctx->dQCount + b, qout,
+                               ctx->dQCount + b + 1, ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
+        else
+            hipLaunchKernelGGL(k_shade<false>, grid, blk, 0, st, sv, ctx->tile, ctx->params, b, qin, ctx->dQCount + b, qout,
+                               ctx->dQCount + b + 1, ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
         rt_timer_end(ctx);
     }
     ctx->lastFrame = frames - 1;

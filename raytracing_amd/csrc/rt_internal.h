@@ -170,6 +170,7 @@ struct RtContext {
     uint32_t *dSmQueue = nullptr;         // ShadowMap pass: shaded path slots
     float *dSeeds = nullptr;              // per-frame seeds of the batch in flight
     bool optPacketShadow = false, optPacketPrimary = false, optPacketTrace = false;
+    bool optMaterialSort = true;
     uint32_t optBatchFrames = 0;          // 0 = by path count (rt_batch_frames)
     uint32_t batchCap = 0;                // frames the path-state buffers can hold
     uint32_t lastFrame = 0;               // frame of the batch that RT_IMAGE_RT / RT_IMAGE_SHADOWMAP show
