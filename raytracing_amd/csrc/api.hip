@@ -121,6 +121,9 @@ int rt_create(int device_id, RtContext **out_ctx)
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) ctx->numCU = cus;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void **)&ctx->dStats, 64 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&ctx->dErrorFlag, 4) != hipSuccess || hipMalloc((void **)&ctx->dQCount, RT_COUNTER_BLOCK_WORDS * 4) != hipSuccess ||
         hipMalloc((void **)&ctx->dStackSpill, (size_t)ctx->numCU * RT_SPILL_WORDS_PER_CU * 4) != hipSuccess) {
@@ -147,6 +150,9 @@ int rt_destroy(RtContext *ctx)
                     ctx->dDisc, ctx->dCube, ctx->dStats, ctx->dErrorFlag, ctx->dQCount, ctx->dStackSpill};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2), (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
+    if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RT_OK;
@@ -494,6 +500,7 @@ int rt_set_option(RtContext *ctx, int option, int value)
     case RT_OPT_PACKET_PRIMARY: ctx->optPacketPrimary = value != 0; return RT_OK;
     case RT_OPT_PACKET_TRACE: ctx->optPacketTrace = value != 0; return RT_OK;
     case RT_OPT_MATERIAL_SORT: ctx->optMaterialSort = value != 0; return RT_OK;
+    case RT_OPT_TWO_STREAMS: ctx->optTwoStreams = value != 0; return RT_OK;
     case RT_OPT_BATCH_FRAMES:
         if (value < 0 || value > 64) return rt_fail(ctx, RT_E_INVALID, "RT_OPT_BATCH_FRAMES must be 0..64");
         ctx->optBatchFrames = (uint32_t)value;

@@ -773,7 +773,51 @@ int rt_accumulate_impl(RtContext *ctx, uint32_t samplePerPixel, int useShadowMap
     return accumulate_frames(ctx, 1, samplePerPixel, useShadowMap, ctx->lastFrame);
 }
 
-// n x CustomRender, `batch` frames in flight at a time.
+// While alive, every per-path buffer of the context points `firstFrame` frames further on, work goes to
+// `stream` and the queue counters to `counters`: the launch helpers above then work on a sub-range of the
+// frames in flight without knowing it.
+struct RtLaneScope {
+    RtContext *ctx;
+    hipStream_t stream;
+    float4 *rt, *sm, *po, *pd, *pe, *smRec;
+    uint2 *rng;
+    RtHitRec *hit;
+    uint32_t *q0, *q1, *smq, *cnt;
+    uint8_t *smFlags;
+    float *seeds;
+    RtLaneScope(RtContext *c, hipStream_t s, uint32_t firstFrame, uint32_t *counters)
+        : ctx(c), stream(c->stream), rt(c->dRt), sm(c->dShadowMap), po(c->dPo), pd(c->dPd), pe(c->dPe), smRec(c->dSmRec), rng(c->dRng),
+          hit(c->dHit), q0(c->dQueue[0]), q1(c->dQueue[1]), smq(c->dSmQueue), cnt(c->dQCount), smFlags(c->dSmFlags), seeds(c->dSeeds)
+    {
+        const size_t off = (size_t)firstFrame * c->tile.nSlots;
+        c->stream = s;
+        c->dRt += off; c->dShadowMap += off; c->dPo += off; c->dPd += off; c->dPe += off; c->dRng += off; c->dHit += off;
+        c->dQueue[0] += off; c->dQueue[1] += off; c->dSmQueue += off; c->dSmRec += 2 * off; c->dSmFlags += 16 * off;
+        c->dSeeds += firstFrame;
+        c->dQCount = counters;
+    }
+    ~RtLaneScope()
+    {
+        RtContext *c = ctx;
+        c->stream = stream;
+        c->dRt = rt; c->dShadowMap = sm; c->dPo = po; c->dPd = pd; c->dPe = pe; c->dSmRec = smRec; c->dRng = rng; c->dHit = hit;
+        c->dQueue[0] = q0; c->dQueue[1] = q1; c->dSmQueue = smq; c->dQCount = cnt; c->dSmFlags = smFlags; c->dSeeds = seeds;
+    }
+};
+
+static int render_lane(RtContext *ctx, uint32_t frames, bool matte, bool shared)
+{
+    int rc = dispatch_frames(ctx, frames, shared);
+    if (rc) return rc;
+    if (matte) {
+        if (shared) launch_shadow_rays(ctx, rt_scene_view(ctx), ctx->tile.nSlots * frames);
+        else rc = shadowmap_frames(ctx, frames);
+    }
+    return rc;
+}
+
+// n x CustomRender, `batch` frames in flight at a time.  With RT_OPT_TWO_STREAMS the frames of a batch go
+// down two streams (first half / second half) so that one half's launch tails overlap the other half's work.
 int rt_render_frames_impl(RtContext *ctx, const float *seeds, uint32_t nFrames)
 {
     const bool matte = (ctx->params.flags & RT_FLAG_MATTE_MASK) != 0;
@@ -784,11 +828,21 @@ int rt_render_frames_impl(RtContext *ctx, const float *seeds, uint32_t nFrames)
     for (uint32_t base = 0; base < nFrames; base += batch) {
         const uint32_t f = nFrames - base < batch ? nFrames - base : batch;
         if ((rc = upload_seeds(ctx, seeds + base, f))) return rc;
-        if ((rc = dispatch_frames(ctx, f, shared))) return rc;
-        if (matte) {
-            if (shared) launch_shadow_rays(ctx, rt_scene_view(ctx), ctx->tile.nSlots * f);
-            else if ((rc = shadowmap_frames(ctx, f))) return rc;
+        const uint32_t fA = (ctx->optTwoStreams && f >= 2 && ctx->stream2) ? (f + 1) / 2 : f, fB = f - fA;
+        if (fB) {
+            // the second stream starts after the seeds are up (and, by stream order, after the last batch was folded in)
+            RT_HIP(ctx, hipEventRecord(ctx->evFork, ctx->stream));
+            RT_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->evFork, 0));
+            {
+                RtLaneScope lane(ctx, ctx->stream2, fA, ctx->dQCount + 32);
+                rc = render_lane(ctx, fB, matte, shared);
+            }
+            if (rc) return rc;
+            RT_HIP(ctx, hipEventRecord(ctx->evJoin, ctx->stream2));
         }
+        if ((rc = render_lane(ctx, fA, matte, shared))) return rc;
+        if (fB) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evJoin, 0));
+        ctx->lastFrame = f - 1;
         if ((rc = accumulate_frames(ctx, f, ctx->sampleCount, matte ? 1 : 0, 0))) return rc;
         ctx->sampleCount += f;
         ctx->params.seed = seeds[base + f - 1];

@@ -124,6 +124,8 @@ struct RtPendingEvent {
 struct RtContext {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;        // second half of the frames in flight (rt_render_frames)
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
     std::string err;
 
     // inputs
@@ -170,7 +172,7 @@ struct RtContext {
     uint32_t *dSmQueue = nullptr;         // ShadowMap pass: shaded path slots
     float *dSeeds = nullptr;              // per-frame seeds of the batch in flight
     bool optPacketShadow = false, optPacketPrimary = false, optPacketTrace = false;
-    bool optMaterialSort = true;
+    bool optMaterialSort = true, optTwoStreams = false;
     uint32_t optBatchFrames = 0;          // 0 = by path count (rt_batch_frames)
     uint32_t batchCap = 0;                // frames the path-state buffers can hold
     uint32_t lastFrame = 0;               // frame of the batch that RT_IMAGE_RT / RT_IMAGE_SHADOWMAP show

@@ -76,4 +76,4 @@ class RtStats(C.Structure):
                 ("shadowTriTests", C.c_uint64), ("shadowHits", C.c_uint64)]
 
 # rt_set_option
-OPT_PACKET_SHADOW, OPT_PACKET_PRIMARY, OPT_PACKET_TRACE, OPT_BATCH_FRAMES, OPT_MATERIAL_SORT = 0, 1, 2, 3, 4
+OPT_PACKET_SHADOW, OPT_PACKET_PRIMARY, OPT_PACKET_TRACE, OPT_BATCH_FRAMES, OPT_MATERIAL_SORT, OPT_TWO_STREAMS = 0, 1, 2, 3, 4, 5

@@ -256,11 +256,12 @@ def test_packet_walkers_do_not_change_a_bit(core):
         core.set_option(wire.OPT_PACKET_SHADOW, on)
         core.set_option(wire.OPT_PACKET_PRIMARY, on)
         core.set_option(wire.OPT_MATERIAL_SORT, 1 - on)
+        core.set_option(wire.OPT_TWO_STREAMS, on)
         core.set_dirty()
         core.render_frames(seeds)
         images.append((core.readback(wire.IMAGE_CONVERGED), core.readback(wire.IMAGE_SHADOWMAP)))
     core.set_option(wire.OPT_MATERIAL_SORT, 1)
-    H.assert_bits_equal(images[0][0], images[1][0], "converged image, packets on vs off")
+    H.assert_bits_equal(images[0][0], images[1][0], "converged image, options on vs off")
     H.assert_bits_equal(images[0][1], images[1][1], "shadow map, packets on vs off")
     assert (images[0][1][..., 0] < 1).any()
 
