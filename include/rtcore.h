@@ -208,8 +208,11 @@ uint32_t rt_sample_count(RtContext *ctx);
 #define RT_IMAGE_RT        0   /* last 1-spp frame  (RayTracing.rt) */
 #define RT_IMAGE_CONVERGED 1   /* running mean      (RayTracing.convergedRT) */
 #define RT_IMAGE_SHADOWMAP 2   /* RayTracing.shadowMap */
+#define RT_IMAGE_POSTPROCESS 3 /* RayTracing.postProcessRT: what the last rt_post_* call drew */
+#define RT_IMAGE_USER      4   /* a frame handed in with rt_image_upload */
 /* Full-frame float4 readback (width*height*4 floats, row 0 = bottom).  Pixels
- * of tiles owned by other ranks read 0. */
+ * of tiles owned by other ranks read 0.  RT_IMAGE_POSTPROCESS / RT_IMAGE_USER
+ * have the size of the frame they were made from (rt_image_size). */
 int rt_readback(RtContext *ctx, int which, float *dst_rgba);
 /* Same image, but only this rank's tiles in tile-local order, copied to a
  * DEVICE pointer (e.g. a torch tensor) of rt_local_pixel_count()*4 floats, for
@@ -239,6 +242,64 @@ int rt_trace_rays_device(RtContext *ctx, const void *device_origins4, const void
  * 4 sRGB->linear, 5 linear->sRGB, 6 float->uint as bits, 7 the Rand() stream of
  * pixel (x[0],x[1]) with seed y[0], Header.cginc:79-92).  No reference counterpart. */
 int rt_debug_eval(RtContext *ctx, int which, const float *x, const float *y, uint32_t n, float *out);
+
+/* ------------------------------------------------------ post-process chain */
+/* The stages of PostProcessStack (PostProcessStack.cs:43-72), each one
+ * `RenderImage(source, destination)` = Graphics.Blit(source, destination, material).
+ * `src` is an RT_IMAGE_* selector; the destination is always RT_IMAGE_POSTPROCESS
+ * (RayTracing.cs:156 passes convergedRT and postProcessRT).  Note that the
+ * reference's stack hands the SAME source to every enabled stage
+ * (PostProcessStack.cs:29-35, one multicast delegate), so what reaches the
+ * screen is the last enabled stage applied to convergedRT; a host that wants
+ * the stages chained passes RT_IMAGE_POSTPROCESS as src.  Images made from a
+ * tile-sharded context (tileCount > 1) cover only this rank's tiles: gather
+ * first and hand the whole frame in with rt_image_upload. */
+
+/* A whole frame from the host (w*h float4, row 0 = bottom) -> RT_IMAGE_USER.
+ * No reference counterpart: stands for a RenderTexture produced elsewhere. */
+int rt_image_upload(RtContext *ctx, const float *rgba, int32_t width, int32_t height);
+int rt_image_size(RtContext *ctx, int which, int32_t *width, int32_t *height);
+
+/* PostProcessBase.RenderImage (PostProcessBase.cs:29-32) and the stack's own
+ * fallback (PostProcessStack.cs:34): a plain copy. */
+int rt_post_blit(RtContext *ctx, int src);
+/* ColorCorrection.RenderImage (ColorCorrection.cs:22-29, ColorCorrection.shader:46-70) */
+int rt_post_color_correction(RtContext *ctx, int src, float brightness, float saturation, float contrast);
+/* mat.SetTexture("_LutTex", lutTex) (ColorGrading.cs:15,23): width x height float4,
+ * row 0 = v 0 (the bottom row of the image file); sampled with FilterMode.Point and
+ * wrap Repeat as the reference's LUT assets are imported (the .png.meta files under Assets/Textures/Lut). */
+int rt_post_lut_upload(RtContext *ctx, const float *rgba, int32_t width, int32_t height);
+/* ColorGrading.RenderImage (ColorGrading.cs:26-29, ColorGrading.shader:46-68) */
+int rt_post_color_grading(RtContext *ctx, int src);
+
+#ifndef RT_WRAP_CLAMP
+#define RT_WRAP_CLAMP 0
+#define RT_WRAP_REPEAT 1
+#endif
+/* Bloom's public fields (Bloom.cs:7-29) plus the two sampler facts its shaders read. */
+typedef struct RtBloomParams {
+    float luminanceThreshold;     /* 1 */
+    int32_t downSampleStep;       /* 7; >= 2 */
+    int32_t downSampleBlurSize;   /* 5; 1..15 */
+    float downSampleBlurSigma;    /* 1 */
+    int32_t upSampleBlurSize;     /* 5; 1..15 */
+    float upSampleBlurSigma;      /* 1 */
+    float bloomIntensity;         /* 1 */
+    /* `_MainTex_ST.xy` of the down/up-sample materials, which the shaders use as the
+     * tap spacing in uv units (DownSample.shader:80, UpSample.shader:83-84).  A
+     * material made from a shader has (1, 1); {0, 0} here means (1, 1).  A host that
+     * wants texel-spaced taps passes (1/w, 1/h)-like values itself. */
+    float mainTexST[2];
+    int32_t wrapMode;             /* RT_WRAP_CLAMP 0 (RenderTexture default) or RT_WRAP_REPEAT 1 */
+} RtBloomParams;
+/* Bloom.RenderImage (Bloom.cs:41-115; Threshold, DownSample, UpSample, Bloom .shader) */
+int rt_post_bloom(RtContext *ctx, int src, const RtBloomParams *params);
+
+/* SaveTexture.SavePNG up to EncodeToPNG (SaveTexture.cs:23-38,59-90): ReadPixels into an
+ * RGB24 texture (8-bit quantisation of the LINEAR value), LinearToSRGB of the
+ * quantised value, SetPixels (second quantisation).  dst = width*height*3 bytes,
+ * row 0 = bottom. */
+int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
 
 /* ------------------------------------------------------------------ tuning */
 /* Execution knobs; none changes a result bit.  No reference counterpart (the

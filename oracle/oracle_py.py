@@ -184,3 +184,37 @@ def brdf_table(params, material, dirs9):
     m = np.ascontiguousarray(material)
     lib().orc_brdf_table(C.byref(params), _p(m), _p(d), C.c_uint32(len(d)), _p(out))
     return out
+
+
+# ---- post-process chain (oracle/rt_post_oracle.cpp); images are f32[H, W, 4], row 0 = bottom
+def post_color_correction(image, brightness, saturation, contrast):
+    src = np.ascontiguousarray(image, np.float32)
+    dst = np.empty_like(src)
+    lib().orc_post_color_correction(_p(src), _p(dst), C.c_int(src.shape[1]), C.c_int(src.shape[0]), C.c_float(brightness),
+                                    C.c_float(saturation), C.c_float(contrast))
+    return dst
+
+
+def post_color_grading(image, lut):
+    src = np.ascontiguousarray(image, np.float32)
+    t = np.ascontiguousarray(lut, np.float32)
+    dst = np.empty_like(src)
+    lib().orc_post_color_grading(_p(src), _p(dst), C.c_int(src.shape[1]), C.c_int(src.shape[0]), _p(t), C.c_int(t.shape[1]),
+                                 C.c_int(t.shape[0]))
+    return dst
+
+
+def post_bloom(image, bloom_params):
+    src = np.ascontiguousarray(image, np.float32)
+    dst = np.empty_like(src)
+    rc = lib().orc_post_bloom(_p(src), _p(dst), C.c_int(src.shape[1]), C.c_int(src.shape[0]), C.byref(bloom_params))
+    if rc != 0:
+        raise ValueError("bloom: frame too small for the number of down-sample steps")
+    return dst
+
+
+def save_rgb24(image):
+    src = np.ascontiguousarray(image, np.float32)
+    dst = np.zeros(src.shape[:2] + (3,), np.uint8)
+    lib().orc_save_rgb24(_p(src), C.c_int(src.shape[1]), C.c_int(src.shape[0]), _p(dst))
+    return dst

@@ -146,6 +146,7 @@ int rt_destroy(RtContext *ctx)
     for (hipEvent_t e : ctx->eventPool) (void)hipEventDestroy(e);
     rt_free_build(ctx);
     rt_free_render(ctx);
+    rt_free_post(ctx);
     void *ptrs[] = {ctx->dVerts, ctx->dIdx, ctx->dMatIdx, ctx->dShadow, ctx->dMats, ctx->dSphere, ctx->dArea,
                     ctx->dDisc, ctx->dCube, ctx->dStats, ctx->dErrorFlag, ctx->dQCount, ctx->dStackSpill};
     for (void *p : ptrs)
@@ -345,7 +346,9 @@ int rt_set_dirty(RtContext *ctx)
 uint32_t rt_sample_count(RtContext *ctx) { return ctx ? ctx->sampleCount : 0; }
 uint32_t rt_local_pixel_count(RtContext *ctx) { return ctx && ctx->paramsSet ? ctx->tile.nSlots : 0; }
 
-static float4 *image_ptr(RtContext *ctx, int which)
+}   // extern "C"
+
+float4 *rt_image_ptr(RtContext *ctx, int which)
 {
     const size_t off = (size_t)ctx->lastFrame * ctx->tile.nSlots;   // the newest frame of the last batch
     switch (which) {
@@ -356,12 +359,16 @@ static float4 *image_ptr(RtContext *ctx, int which)
     }
 }
 
+extern "C" {
+
 int rt_readback(RtContext *ctx, int which, float *dst_rgba)
 {
     RT_ENTER(ctx);
+    if (!dst_rgba) return rt_fail(ctx, RT_E_INVALID, "null destination");
+    if (which == RT_IMAGE_POSTPROCESS || which == RT_IMAGE_USER) return rt_post_readback_impl(ctx, which, dst_rgba);
     if (!ctx->paramsSet) return rt_fail(ctx, RT_E_STATE, "rt_set_params has not been called");
-    float4 *src = image_ptr(ctx, which);
-    if (!src || !dst_rgba) return rt_fail(ctx, RT_E_INVALID, "bad image selector or null destination");
+    float4 *src = rt_image_ptr(ctx, which);
+    if (!src) return rt_fail(ctx, RT_E_INVALID, "bad image selector %d", which);
     const size_t px = (size_t)ctx->params.width * ctx->params.height;
     float4 *full = nullptr;
     RT_HIP(ctx, hipMalloc((void **)&full, px * sizeof(float4)));
@@ -379,7 +386,7 @@ int rt_readback_local_device(RtContext *ctx, int which, void *device_dst)
 {
     RT_ENTER(ctx);
     if (!ctx->paramsSet) return rt_fail(ctx, RT_E_STATE, "rt_set_params has not been called");
-    float4 *src = image_ptr(ctx, which);
+    float4 *src = rt_image_ptr(ctx, which);
     if (!src || !device_dst) return rt_fail(ctx, RT_E_INVALID, "bad image selector or null destination");
     RT_HIP(ctx, hipMemcpyAsync(device_dst, src, (size_t)ctx->tile.nSlots * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));

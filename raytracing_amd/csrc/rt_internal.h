@@ -121,6 +121,8 @@ struct RtPendingEvent {
 #define RT_COUNTER_BLOCK_WORDS 64   // queue counts (dQCount)
 #define RT_SPILL_WORDS_PER_CU (2048 * RT_STACK_DEPTH)   // room for every stack level of 2048 lanes per CU
 
+struct RtPostState;   // post.hip
+
 struct RtContext {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -191,6 +193,8 @@ struct RtContext {
     std::map<std::string, RtKernelTimer> timers;
     std::vector<RtPendingEvent> pending;
     std::vector<hipEvent_t> eventPool;
+
+    RtPostState *post = nullptr;          // images and scratch of the post-process chain, made on first use
 };
 
 // ---- helpers shared by the translation units -------------------------------
@@ -206,6 +210,13 @@ int rt_fail(RtContext *ctx, int code, const char *fmt, ...);
 void rt_timer_begin(RtContext *ctx, const char *name);
 void rt_timer_end(RtContext *ctx);
 void rt_timer_resolve(RtContext *ctx);
+
+// api.hip
+float4 *rt_image_ptr(RtContext *ctx, int which);   // tile-local device image behind RT_IMAGE_RT / _CONVERGED / _SHADOWMAP
+
+// post.hip
+void rt_free_post(RtContext *ctx);
+int rt_post_readback_impl(RtContext *ctx, int which, float *dst_rgba);
 
 // build.hip
 int rt_build_impl(RtContext *ctx);

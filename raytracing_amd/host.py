@@ -9,6 +9,8 @@ P/Invoke form of the identical calls.  Mirrored:
   BVH                     Assets/Scripts/BVH/BVH.cs:108-352            Init, InitMesh, InitMaterialData, UpdateMaterialData
   LightImportanceSampling Assets/Scripts/RayTracing/LightImportanceSampling.cs:57-107   Init
   DepthOfField            Assets/Scripts/PostProcess/DepthOfField.cs:22-44  UpdateParameter
+  PostProcessStack, ColorCorrection, ColorGrading, Bloom, PostProcessBase   Assets/Scripts/PostProcess/*.cs
+  SaveTexture             Assets/Scripts/SaveTexture.cs:15-90          Save (SavePNG)
 
 Unity objects (Transform, MeshRenderer, Material, Camera) are replaced by small
 data classes holding just the fields those methods read.
@@ -167,12 +169,130 @@ class LightImportanceSampling:
         core.lights_upload(*self.Lights())
 
 
-# ------------------------------------------------------------------ DepthOfField.cs
+# ------------------------------------------------------------------ PostProcess/*.cs
+class PostProcessBase:
+    """PostProcessBase.cs:5-37.  `source` is an IMAGE_* selector of the core; the
+    destination is always the core's IMAGE_POSTPROCESS (RayTracing.cs:156)."""
+    enabled = True
+    core: Optional[RtCore] = None
+
+    def Init(self, core: RtCore):
+        self.core = core
+
+    def RenderImage(self, source):               # :29-32  Graphics.Blit(source, destination)
+        self.core.post_blit(source)
+
+    def UpdateParameter(self):
+        pass
+
+
 @dataclass
-class DepthOfField:
+class DepthOfField(PostProcessBase):
+    """DepthOfField.cs: only feeds _LensRadius/_FocalLength and the DEPTH_OF_FIELD
+    keyword (:22-36); as a stage of the stack it is the base class's plain copy."""
     enabled: bool = False
     focalLength: float = 1.0
     lensRadius: float = 0.0
+
+
+@dataclass
+class ColorCorrection(PostProcessBase):          # ColorCorrection.cs:7-12
+    brightness: float = 0.96
+    saturation: float = 1.33
+    contrast: float = 1.85
+    enabled: bool = True
+
+    def RenderImage(self, source):               # :22-29
+        self.core.post_color_correction(source, self.brightness, self.saturation, self.contrast)
+
+
+@dataclass
+class ColorGrading(PostProcessBase):             # ColorGrading.cs:7
+    lutTex: Optional[np.ndarray] = None          # f32[H, W, 4], row 0 = v 0
+    enabled: bool = True
+
+    def Init(self, core: RtCore):                # Start: mat.SetTexture("_LutTex", lutTex)  (:10-16)
+        super().Init(core)
+        if self.lutTex is not None:
+            core.post_lut_upload(self.lutTex)
+
+    def RenderImage(self, source):               # :26-29
+        self.core.post_color_grading(source)
+
+
+@dataclass
+class Bloom(PostProcessBase):                    # Bloom.cs:7-29
+    luminanceThreshold: float = 1.0
+    downSampleStep: int = 7
+    downSampleBlurSize: int = 5
+    downSampleBlurSigma: float = 1.0
+    upSampleBlurSize: int = 5
+    upSampleBlurSigma: float = 1.0
+    bloomIntensity: float = 1.0
+    enabled: bool = True
+
+    def Parameters(self):
+        return wire.RtBloomParams(luminanceThreshold=self.luminanceThreshold, downSampleStep=self.downSampleStep,
+                                  downSampleBlurSize=self.downSampleBlurSize, downSampleBlurSigma=self.downSampleBlurSigma,
+                                  upSampleBlurSize=self.upSampleBlurSize, upSampleBlurSigma=self.upSampleBlurSigma,
+                                  bloomIntensity=self.bloomIntensity)
+
+    def RenderImage(self, source):               # :41-115
+        self.core.post_bloom(source, self.Parameters())
+
+
+class PostProcessStack:
+    """PostProcessStack.cs.  The three delegates are multicast: Render hands the SAME
+    source to every bound stage in binding order, each drawing over the destination
+    (:29-35), so the destination ends up holding the last bound stage's output."""
+
+    def __init__(self, colorCorrection=None, colorGrading=None, bloom=None, dof=None):
+        self.colorCorrection, self.colorGrading, self.bloom, self.dof = colorCorrection, colorGrading, bloom, dof
+        self.renderers, self.updates, self.inits = [], [], []
+
+    def Init(self, core: RtCore):                # :21-27
+        self.core = core
+        self.Bind()
+        for init in self.inits:
+            init(core)
+
+    def Render(self, source=wire.IMAGE_CONVERGED):   # :29-35
+        if self.renderers:
+            for render in self.renderers:
+                render(source)
+        else:
+            self.core.post_blit(source)
+
+    def UpdateParameter(self):                   # :37-41
+        for update in self.updates:
+            update()
+
+    def Bind(self):                              # :43-72
+        self.renderers, self.updates, self.inits = [], [], []
+        for stage in (self.colorCorrection, self.colorGrading, self.bloom):
+            if stage is not None and stage.enabled:
+                self.inits.append(stage.Init)
+                self.renderers.append(stage.RenderImage)
+                self.updates.append(stage.UpdateParameter)
+        if self.dof is not None:                 # :66 -- bound whether enabled or not
+            self.inits.append(self.dof.Init)
+            self.renderers.append(self.dof.RenderImage)
+            self.updates.append(self.dof.UpdateParameter)
+
+
+class SaveTexture:
+    """SaveTexture.cs: the 8-bit sRGB image its SavePNG hands to EncodeToPNG (:23-38)."""
+
+    def __init__(self, rayTracing):
+        self.rayTracing = rayTracing
+
+    def Pixels(self, which=wire.IMAGE_CONVERGED):
+        return self.rayTracing.core.save_rgb24(which)        # u8[H, W, 3], row 0 = bottom
+
+    def Save(self, path, which=wire.IMAGE_CONVERGED):         # :15-21 saves convergedRT
+        from .ingest import png
+        png.write_png(path, self.Pixels(which)[::-1])         # PNG rows run top to bottom
+        return path
 
 
 # ------------------------------------------------------------------ RayTracing.cs
@@ -201,6 +321,8 @@ class RayTracing:
         self.matteMaskGO = None
         self.pause = False
         self.depthOfField = DepthOfField()
+        self.postProcessStack: Optional[PostProcessStack] = None
+        self.enablePostProcess = False
         self.isInitialized = False
         self.isRenderMatteMask = False
         self.core: Optional[RtCore] = None
@@ -226,6 +348,8 @@ class RayTracing:
 
     def InitShader(self):                        # :190-217
         self.core.skybox_upload(self.skybox)
+        if self.enablePostProcess:               # :215-216
+            self.postProcessStack.Init(self.core)
 
     def InitLight(self):                         # :254-282
         self.lightImportanceSampling.Init(self.core)
@@ -273,11 +397,16 @@ class RayTracing:
         if not self.aliasing:
             return self.core.readback(wire.IMAGE_RT)
         self.core.accumulate(self.samplePrePixel, self.isRenderMatteMask)
+        if self.enablePostProcess:               # :154-158
+            self.postProcessStack.Render(wire.IMAGE_CONVERGED)
         self.samplePrePixel += 1
         return None
 
     def convergedRT(self):
         return self.core.readback(wire.IMAGE_CONVERGED)
+
+    def postProcessRT(self):
+        return self.core.readback(wire.IMAGE_POSTPROCESS)
 
     def SetDirty(self):                          # :314-317
         self.samplePrePixel = 0

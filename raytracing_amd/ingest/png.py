@@ -76,3 +76,18 @@ def linear_to_srgb8(rgb):
     x = np.clip(np.asarray(rgb, np.float64), 0.0, 1.0)
     s = np.where(x <= 0.0031308, x * 12.92, 1.055 * np.power(x, 1 / 2.4) - 0.055)
     return (s * 255.0 + 0.5).astype(np.uint8)
+
+
+def texture_from_u8(image_u8_bottom_up):
+    """8-bit texels (row 0 = v 0) -> the f32[H, W, 4] UNORM values a sampler returns for a
+    linear (sRGBTexture: 0) texture; a missing alpha channel reads 1."""
+    img = np.asarray(image_u8_bottom_up, np.uint8)
+    out = np.ones(img.shape[:2] + (4,), np.float32)
+    out[..., :img.shape[2]] = img.astype(np.float32) / np.float32(255.0)
+    return out
+
+
+def read_texture(path):
+    """A PNG as the texture Unity makes of it when imported linear: f32[H, W, 4], row 0 = the
+    bottom row of the file (v = 0)."""
+    return texture_from_u8(read_png(path)[::-1])

@@ -22,6 +22,8 @@ EXPORTS = [
     "rt_readback_local_device", "rt_upload_converged", "rt_local_pixel_count", "rt_local_pixel_map", "rt_trace_rays",
     "rt_trace_rays_device", "rt_enable_counters", "rt_enable_kernel_timing", "rt_reset_stats", "rt_get_stats",
     "rt_kernel_time", "rt_synchronize", "rt_version", "rt_debug_eval", "rt_set_option",
+    "rt_image_upload", "rt_image_size", "rt_post_blit", "rt_post_color_correction", "rt_post_lut_upload",
+    "rt_post_color_grading", "rt_post_bloom", "rt_save_rgb24",
 ]
 
 _lib = None
@@ -161,7 +163,8 @@ class RtCore:
         return int(self.lib.rt_sample_count(self.ctx))
 
     def readback(self, which=wire.IMAGE_CONVERGED):
-        img = np.zeros((self.params.height, self.params.width, 4), np.float32)
+        w, h = self.image_size(which)
+        img = np.zeros((h, w, 4), np.float32)
         self._check(self.lib.rt_readback(self.ctx, C.c_int(which), _p(img)))
         return img
 
@@ -200,6 +203,41 @@ class RtCore:
         n = x.size if n is None else n
         out = np.zeros(n, np.float32)
         self._check(self.lib.rt_debug_eval(self.ctx, C.c_int(which), _p(x), _p(y), C.c_uint32(n), _p(out)))
+        return out
+
+    # ---- post-process chain (whole frames; the destination is always IMAGE_POSTPROCESS)
+    def image_upload(self, image):
+        img = np.ascontiguousarray(image, np.float32)
+        assert img.ndim == 3 and img.shape[2] == 4
+        self._check(self.lib.rt_image_upload(self.ctx, _p(img), C.c_int32(img.shape[1]), C.c_int32(img.shape[0])))
+
+    def image_size(self, which):
+        w, h = C.c_int32(), C.c_int32()
+        self._check(self.lib.rt_image_size(self.ctx, C.c_int(which), C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def post_blit(self, src=wire.IMAGE_CONVERGED):
+        self._check(self.lib.rt_post_blit(self.ctx, C.c_int(src)))
+
+    def post_color_correction(self, src, brightness, saturation, contrast):
+        self._check(self.lib.rt_post_color_correction(self.ctx, C.c_int(src), C.c_float(brightness), C.c_float(saturation),
+                                                      C.c_float(contrast)))
+
+    def post_lut_upload(self, lut):
+        t = np.ascontiguousarray(lut, np.float32)
+        assert t.ndim == 3 and t.shape[2] == 4
+        self._check(self.lib.rt_post_lut_upload(self.ctx, _p(t), C.c_int32(t.shape[1]), C.c_int32(t.shape[0])))
+
+    def post_color_grading(self, src):
+        self._check(self.lib.rt_post_color_grading(self.ctx, C.c_int(src)))
+
+    def post_bloom(self, src, bloom_params):
+        self._check(self.lib.rt_post_bloom(self.ctx, C.c_int(src), C.byref(bloom_params)))
+
+    def save_rgb24(self, which=wire.IMAGE_CONVERGED):
+        w, h = self.image_size(which)
+        out = np.zeros((h, w, 3), np.uint8)
+        self._check(self.lib.rt_save_rgb24(self.ctx, C.c_int(which), _p(out)))
         return out
 
     # ---- tuning

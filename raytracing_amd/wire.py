@@ -44,7 +44,8 @@ FLAG_DEPTH_OF_FIELD = 0x10
 FLAG_DOF_PRIMARY = 0x20
 FLAG_MATTE_MASK = 0x40
 
-IMAGE_RT, IMAGE_CONVERGED, IMAGE_SHADOWMAP = 0, 1, 2
+IMAGE_RT, IMAGE_CONVERGED, IMAGE_SHADOWMAP, IMAGE_POSTPROCESS, IMAGE_USER = 0, 1, 2, 3, 4
+WRAP_CLAMP, WRAP_REPEAT = 0, 1
 
 
 class RtParams(C.Structure):
@@ -77,3 +78,24 @@ class RtStats(C.Structure):
 
 # rt_set_option
 OPT_PACKET_SHADOW, OPT_PACKET_PRIMARY, OPT_PACKET_TRACE, OPT_BATCH_FRAMES, OPT_MATERIAL_SORT, OPT_TWO_STREAMS = 0, 1, 2, 3, 4, 5
+
+
+class RtBloomParams(C.Structure):
+    """Bloom's public fields with their defaults (Bloom.cs:7-29)."""
+    _fields_ = [("luminanceThreshold", C.c_float), ("downSampleStep", C.c_int32), ("downSampleBlurSize", C.c_int32),
+                ("downSampleBlurSigma", C.c_float), ("upSampleBlurSize", C.c_int32), ("upSampleBlurSigma", C.c_float),
+                ("bloomIntensity", C.c_float), ("mainTexST", C.c_float * 2), ("wrapMode", C.c_int32)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.luminanceThreshold, self.downSampleStep = 1.0, 7
+        self.downSampleBlurSize, self.downSampleBlurSigma = 5, 1.0
+        self.upSampleBlurSize, self.upSampleBlurSigma = 5, 1.0
+        self.bloomIntensity = 1.0
+        self.mainTexST[0], self.mainTexST[1] = 1.0, 1.0
+        self.wrapMode = WRAP_CLAMP
+        for k, v in kw.items():
+            if k == "mainTexST":
+                self.mainTexST[0], self.mainTexST[1] = v
+            else:
+                setattr(self, k, v)
