@@ -17,7 +17,8 @@ public static class RtCoreNative
 
     public const int RT_OK = 0, RT_E_INVALID = -1, RT_E_DEVICE = -2, RT_E_NOMEM = -3, RT_E_STATE = -4, RT_E_OVERFLOW = -5;
     public const uint RT_FLAG_DEPTH_OF_FIELD = 0x10, RT_FLAG_DOF_PRIMARY = 0x20, RT_FLAG_MATTE_MASK = 0x40;
-    public const int RT_IMAGE_RT = 0, RT_IMAGE_CONVERGED = 1, RT_IMAGE_SHADOWMAP = 2;
+    public const int RT_IMAGE_RT = 0, RT_IMAGE_CONVERGED = 1, RT_IMAGE_SHADOWMAP = 2, RT_IMAGE_POSTPROCESS = 3, RT_IMAGE_USER = 4;
+    public const int RT_WRAP_CLAMP = 0, RT_WRAP_REPEAT = 1;
 
     [StructLayout(LayoutKind.Sequential)]
     public struct MeshVertex { public Vector3 position, normal, tangent; public Vector2 uv; }          // 44 B
@@ -47,7 +48,20 @@ public static class RtCoreNative
     }
 
     [StructLayout(LayoutKind.Sequential)]
-    public struct RtStats { public ulong rays, internalVisits, leafVisits, triTests, hits, paths; public double buildMs, renderMs; }
+    public struct RtStats
+    {
+        public ulong rays, internalVisits, leafVisits, triTests, hits, paths; public double buildMs, renderMs;
+        public ulong shadowRays, shadowInternalVisits, shadowLeafVisits, shadowTriTests, shadowHits;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct RtBloomParams                      // Bloom.cs:7-29 + the two sampler facts its shaders read
+    {
+        public float luminanceThreshold; public int downSampleStep, downSampleBlurSize; public float downSampleBlurSigma;
+        public int upSampleBlurSize; public float upSampleBlurSigma, bloomIntensity;
+        public Vector2 mainTexST;                    // (0,0) = the material default (1,1)
+        public int wrapMode;
+    }
 
     [DllImport(Lib)] public static extern int rt_create(int deviceId, out IntPtr ctx);
     [DllImport(Lib)] public static extern int rt_destroy(IntPtr ctx);
@@ -71,6 +85,17 @@ public static class RtCoreNative
     [DllImport(Lib)] public static extern int rt_readback(IntPtr ctx, int which, Color[] dstRgba);     // Color = 4 floats
     [DllImport(Lib)] public static extern int rt_upload_converged(IntPtr ctx, Color[] srcRgba, uint samplePerPixel);
     [DllImport(Lib)] public static extern int rt_get_stats(IntPtr ctx, out RtStats stats);
+    [DllImport(Lib)] public static extern int rt_set_option(IntPtr ctx, int option, int value);
+
+    // post-process chain: the destination is always RT_IMAGE_POSTPROCESS (RayTracing.postProcessRT)
+    [DllImport(Lib)] public static extern int rt_image_upload(IntPtr ctx, Color[] rgba, int width, int height);
+    [DllImport(Lib)] public static extern int rt_image_size(IntPtr ctx, int which, out int width, out int height);
+    [DllImport(Lib)] public static extern int rt_post_blit(IntPtr ctx, int src);
+    [DllImport(Lib)] public static extern int rt_post_color_correction(IntPtr ctx, int src, float brightness, float saturation, float contrast);
+    [DllImport(Lib)] public static extern int rt_post_lut_upload(IntPtr ctx, Color[] rgba, int width, int height);
+    [DllImport(Lib)] public static extern int rt_post_color_grading(IntPtr ctx, int src);
+    [DllImport(Lib)] public static extern int rt_post_bloom(IntPtr ctx, int src, ref RtBloomParams p);
+    [DllImport(Lib)] public static extern int rt_save_rgb24(IntPtr ctx, int which, byte[] dstRgb);
 
     public static void Check(IntPtr ctx, int rc)
     {
