@@ -86,6 +86,26 @@ typedef struct RtSphereLight { float position[3]; float radius; } RtSphereLight;
 typedef struct RtAreaLight { float position[3]; float normal[3]; float up[3]; float size[2]; } RtAreaLight; /* 44 B */
 typedef struct RtDiscLight { float position[3]; float normal[3]; float radius; } RtDiscLight; /* 28 B */
 
+/* Brute-force primitives of chapters 2-4 (useBVH = false): the GPU structs of
+ * BruteForceRayTracing.cginc:5-65 = MeshCollector.cs:46-156, field for field. */
+typedef struct RtPlane {
+    float normal[3], position[3], size[3];
+    float albedo[3]; float metallic, smoothness, transparent; float emissionColor[3];
+} RtPlane;                                  /* 72 B */
+typedef struct RtSphere {
+    float center[3]; float radius;
+    float albedo[3]; float metallic, smoothness, transparent; float emissionColor[3];
+} RtSphere;                                 /* 52 B */
+typedef struct RtCube {
+    float min[3], max[3];
+    float albedo[3]; float metallic, smoothness, transparent; float emissionColor[3];
+} RtCube;                                   /* 60 B */
+typedef struct RtCustomMesh {
+    float localToWorldMatrix[16];           /* Unity memory order */
+    int32_t indicesOffset, indicesCount;
+    float albedo[3]; float metallic, smoothness, transparent; float emissionColor[3];
+} RtCustomMesh;                             /* 108 B */
+
 /* ------------------------------------------------------------------ flags */
 /* RayTracing.cs:40-48 (SamplingType) -> bits 0..2 */
 #define RT_SAMPLING_UNIFORM   0u
@@ -101,6 +121,10 @@ typedef struct RtDiscLight { float position[3]; float normal[3]; float radius; }
 #define RT_FLAG_DOF_PRIMARY      0x20u
 /* RayTracing.cs:178-182: a matte-mask object exists -> ShadowMap pass runs. */
 #define RT_FLAG_MATTE_MASK       0x40u
+/* RayTracing.cs:84-93: useBVH = false -> cs.DisableKeyword("BVH"); CSMain then calls
+ * BruteForceRayTrace over the rt_primitives_upload lists (RayTracing.compute:73-77).
+ * The ShadowMap kernel always walks the BVH (RayTracing.compute:112). */
+#define RT_FLAG_BRUTE_FORCE      0x80u
 
 /* POD mirror of every uniform the reference sets on RayTracing.compute:
  * RayTracing.cs:194-204,223-230,256-260; DepthOfField.cs:22-36. */
@@ -169,6 +193,28 @@ int rt_lights_upload(RtContext *ctx, const RtSphereLight *sphere, uint32_t n_sph
  * images of size x size RGBA float32 in D3D face order +X,-X,+Y,-Y,+Z,-Z,
  * each row-major with v downwards.  size = 0 unbinds (samples read 0). */
 int rt_skybox_upload(RtContext *ctx, const float *faces_rgba, uint32_t size);
+
+/* MeshCollector.Init (MeshCollector.cs:170-200, 271-307): the four primitive lists in
+ * the order the host sorted them (far to near, :279-290) and the merged vertex /
+ * normal / index buffers of the custom meshes (3 floats per vertex; indices already
+ * offset per mesh, :138-152).  The reference uploads one zeroed element for an empty
+ * list (:299-300); the caller does the same if it wants that behaviour, a count of 0
+ * simply skips the list.  indicesCount must be a multiple of 3 and every index < n_vertices. */
+int rt_primitives_upload(RtContext *ctx, const RtPlane *planes, uint32_t n_planes, const RtSphere *spheres, uint32_t n_spheres,
+                         const RtCube *cubes, uint32_t n_cubes, const RtCustomMesh *meshes, uint32_t n_meshes,
+                         const float *vertices3, const float *normals3, uint32_t n_vertices,
+                         const int32_t *indices, uint32_t n_indices);
+/* BruteForceRayTrace (BruteForceRayTracing.cginc:246-279) for a batch of caller rays.
+ * Outputs (any may be NULL): hit.distance (inf when Shade would see a miss), the
+ * primitive that wrote the hit last as kind << 28 | index (kind 0 plane, 1 sphere,
+ * 2 cube, 3 custom-mesh triangle counted over all meshes in list order; 0xFFFFFFFF
+ * on a miss) and hit.normal (n x 3). */
+#define RT_PRIM_PLANE 0u
+#define RT_PRIM_SPHERE 1u
+#define RT_PRIM_CUBE 2u
+#define RT_PRIM_TRIANGLE 3u
+int rt_trace_primitives(RtContext *ctx, const float *origins, const float *directions, uint32_t n,
+                        float *out_t, uint32_t *out_primitive, float *out_normal);
 
 /* --------------------------------------------------------------- BVH build */
 /* MeshData.Calculate + ComputeBufferSorter.Sort + DistributeMortonCode +

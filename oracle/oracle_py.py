@@ -54,6 +54,23 @@ class Oracle:
             sk = np.ascontiguousarray(scene.skybox, np.float32)
             L.orc_set_skybox(self.h, _p(sk), C.c_uint32(sk.shape[1]))
         self.built = False
+        pr = getattr(scene, "primitives", None)
+        if pr is not None:
+            pl, sp, cu, me = (np.ascontiguousarray(x) for x in (pr.planes, pr.spheres, pr.cubes, pr.meshes))
+            v = np.ascontiguousarray(pr.vertices, np.float32).reshape(-1, 3)
+            nr = np.ascontiguousarray(pr.normals, np.float32).reshape(-1, 3)
+            ix = np.ascontiguousarray(pr.indices, np.int32)
+            L.orc_set_primitives(self.h, _p(pl), C.c_uint32(len(pl)), _p(sp), C.c_uint32(len(sp)), _p(cu), C.c_uint32(len(cu)),
+                                 _p(me), C.c_uint32(len(me)), _p(v), _p(nr), C.c_uint32(len(v)), _p(ix), C.c_uint32(len(ix)))
+
+    def trace_primitives(self, origins, directions):
+        """BruteForceRayTrace for caller rays -> dict(t, primitive, normal)."""
+        o = np.ascontiguousarray(origins, np.float32)
+        d = np.ascontiguousarray(directions, np.float32)
+        n = len(o)
+        t, prim, nrm = np.zeros(n, np.float32), np.zeros(n, np.uint32), np.zeros((n, 3), np.float32)
+        lib().orc_trace_primitives(self.h, _p(o), _p(d), C.c_uint32(n), _p(t), _p(prim), _p(nrm))
+        return dict(t=t, primitive=prim, normal=nrm)
 
     def __del__(self):
         try:

@@ -77,6 +77,14 @@ struct Scene {
     std::vector<float> cube;           // 6 * size * size * 4
     uint32_t cubeSize = 0;
 
+    // brute-force primitives (MeshCollector.cs:170-200)
+    std::vector<RtPlane> planeBuffer;
+    std::vector<RtSphere> sphereBuffer;
+    std::vector<RtCube> cubeBuffer;
+    std::vector<RtCustomMesh> customMeshBuffer;
+    std::vector<f3> vertexBuffer, normalBuffer;
+    std::vector<int32_t> indexBuffer;
+
     // build products (wire structs)
     std::vector<RtAABB> triAABB;
     std::vector<RtTriangle> tris;
@@ -555,15 +563,156 @@ RayHit BVHRayTrace(const Thread &th, const Ray &ray)
     return hit;
 }
 
-// ------------------------------------------------------------------ a7 / a8
-inline float Rand(Thread &th) { return rt_rand(&th.rng); }     // Header.cginc:86-92
-
 // 4x4 (Unity memory order) times float4; rows summed left to right.
 inline void mul44(const float *m, float x, float y, float z, float w, float out[4])
 {
     for (int r = 0; r < 4; ++r)
         out[r] = ((m[0 * 4 + r] * x + m[1 * 4 + r] * y) + m[2 * 4 + r] * z) + m[3 * 4 + r] * w;
 }
+
+// ------------------------------------------------------------------ BruteForceRayTracing.cginc
+// The RayHit fields only IntersectPlane writes (materialType, ior, clearCoatColor, shadow flags)
+// keep whatever an earlier primitive left there, as in the shader; `primitive` (not in the
+// reference) remembers who wrote the hit last: kind << 28 | index.
+inline f3 mulPoint(const float *m, f3 v, float w)
+{
+    float out[4];
+    mul44(m, v.x, v.y, v.z, w, out);
+    return rt_mk3(out[0], out[1], out[2]);
+}
+
+// :68-99
+void IntersectPlane(const Ray &ray, const RtPlane &plane, uint32_t index, RayHit &hit)
+{
+    const f3 normal = ld3(plane.normal), position = ld3(plane.position), size = ld3(plane.size);
+    const float t = rt_dot3(normal, rt_sub3(position, ray.origin)) / rt_dot3(normal, ray.direction);
+    if (t > 0 && t < hit.distance) {
+        const f3 mn = rt_sub3(position, rt_divs3(size, 2.0f));
+        const f3 mx = rt_add3(position, rt_divs3(size, 2.0f));
+        const f3 p = rt_add3(ray.origin, rt_scale3(ray.direction, t));
+        if (p.x > mn.x && p.x < mx.x && p.y > mn.y && p.y < mx.y && p.z > mn.z && p.z < mx.z) {
+            hit.distance = t;
+            hit.position = p;
+            hit.normal = normal;
+            hit.albedo = ld3(plane.albedo);
+            hit.metallic = plane.metallic;
+            hit.smoothness = plane.smoothness;
+            hit.transparent = plane.transparent;
+            hit.emissionColor = ld3(plane.emissionColor);
+            hit.materialType = 0;
+            hit.ior = 1.0f;
+            hit.clearCoatColor = rt_splat3(0.0f);
+            hit.castShadow = 0;
+            hit.receiveShadow = 0;
+            hit.triangle = (RT_PRIM_PLANE << 28) | index;
+        }
+    }
+}
+
+// :101-130
+void IntersectSphere(const Ray &ray, const RtSphere &sphere, uint32_t index, RayHit &hit)
+{
+    const f3 center = ld3(sphere.center);
+    const float distance = rt_length3(rt_sub3(center, ray.origin));
+    if (distance < sphere.radius) return;
+    const f3 dir = rt_sub3(center, ray.origin);
+    const float l = rt_dot3(dir, rt_normalize3(ray.direction));
+    if (l < 0) return;
+    const float m = rt_sqrt(distance * distance - l * l);
+    if (m > sphere.radius) return;
+    const float q = rt_sqrt(sphere.radius * sphere.radius - m * m);
+    hit.distance = l - q;
+    hit.position = rt_add3(ray.origin, rt_scale3(ray.direction, l - q));
+    hit.normal = rt_normalize3(rt_sub3(hit.position, center));
+    hit.albedo = ld3(sphere.albedo);
+    hit.metallic = sphere.metallic;
+    hit.smoothness = sphere.smoothness;
+    hit.transparent = sphere.transparent;
+    hit.emissionColor = ld3(sphere.emissionColor);
+    hit.triangle = (RT_PRIM_SPHERE << 28) | index;
+}
+
+// :132-163
+void IntersectCube(const Ray &ray, const RtCube &cube, uint32_t index, RayHit &hit)
+{
+    const f3 cmin = ld3(cube.min), cmax = ld3(cube.max);
+    const f3 invDir = rt_div3(rt_splat3(1.0f), ray.direction);
+    const f3 tMin = rt_mul3(rt_sub3(cmin, ray.origin), invDir);
+    const f3 tMax = rt_mul3(rt_sub3(cmax, ray.origin), invDir);
+    const f3 t1 = rt_mk3(rt_min(tMin.x, tMax.x), rt_min(tMin.y, tMax.y), rt_min(tMin.z, tMax.z));
+    const f3 t2 = rt_mk3(rt_max(tMin.x, tMax.x), rt_max(tMin.y, tMax.y), rt_max(tMin.z, tMax.z));
+    const float tNear = rt_max(rt_max(t1.x, t1.y), t1.z);
+    const float tFar = rt_min(rt_min(t2.x, t2.y), t2.z);
+    if (tNear > tFar) return;
+    f3 normal = rt_mk3(1, 0, 0);
+    if (tNear == t1.y) normal = rt_mk3(0, 1, 0);
+    else if (tNear == t1.z) normal = rt_mk3(0, 0, 1);
+    const f3 side = rt_sub3(ray.origin, rt_scale3(rt_add3(cmin, cmax), 0.5f));
+    normal = rt_mul3(normal, rt_mk3(rt_sign(side.x), rt_sign(side.y), rt_sign(side.z)));
+    hit.distance = tNear;
+    hit.position = rt_add3(ray.origin, rt_scale3(ray.direction, tNear));
+    hit.normal = normal;
+    hit.albedo = ld3(cube.albedo);
+    hit.metallic = cube.metallic;
+    hit.smoothness = cube.smoothness;
+    hit.transparent = cube.transparent;
+    hit.emissionColor = ld3(cube.emissionColor);
+    hit.triangle = (RT_PRIM_CUBE << 28) | index;
+}
+
+// :206-243; `firstTriangle` numbers the triangles over all meshes in list order
+void IntersectCustomMesh(const Scene &s, const Ray &ray, const RtCustomMesh &mesh, uint32_t firstTriangle, RayHit &hit)
+{
+    const uint32_t offset = (uint32_t)mesh.indicesOffset;
+    const uint32_t count = offset + (uint32_t)mesh.indicesCount;
+    uint32_t tri = firstTriangle;
+    for (uint32_t i = offset; i < count; i += 3, ++tri) {
+        const f3 v0 = mulPoint(mesh.localToWorldMatrix, s.vertexBuffer[s.indexBuffer[i]], 1);
+        const f3 v1 = mulPoint(mesh.localToWorldMatrix, s.vertexBuffer[s.indexBuffer[i + 1]], 1);
+        const f3 v2 = mulPoint(mesh.localToWorldMatrix, s.vertexBuffer[s.indexBuffer[i + 2]], 1);
+        const f3 n0 = mulPoint(mesh.localToWorldMatrix, s.normalBuffer[s.indexBuffer[i]], 0);
+        const f3 n1 = mulPoint(mesh.localToWorldMatrix, s.normalBuffer[s.indexBuffer[i + 1]], 0);
+        const f3 n2 = mulPoint(mesh.localToWorldMatrix, s.normalBuffer[s.indexBuffer[i + 2]], 0);
+        float t = 0, u = 0, v = 0;
+        if (IntersectTriangle_MT97(ray, v0, v1, v2, t, u, v)) {
+            if (t > 0 && t < hit.distance) {
+                hit.distance = t;
+                hit.position = rt_add3(ray.origin, rt_scale3(ray.direction, t));
+                hit.normal = rt_normalize3(rt_add3(rt_add3(rt_scale3(n0, (1 - u) - v), rt_scale3(n1, u)), rt_scale3(n2, v)));
+                hit.albedo = ld3(mesh.albedo);
+                hit.metallic = mesh.metallic;
+                hit.smoothness = mesh.smoothness;
+                hit.transparent = mesh.transparent;
+                hit.emissionColor = ld3(mesh.emissionColor);
+                hit.triangle = (RT_PRIM_TRIANGLE << 28) | tri;
+                hit.u = u;
+                hit.v = v;
+            }
+        }
+    }
+}
+
+// :246-279
+RayHit BruteForceRayTrace(const Thread &th, const Ray &ray)
+{
+    const Scene &s = *th.sc;
+    RayHit hit = CreateRayHit();
+    if (th.cnt) th.cnt->rays++;
+    for (size_t i = 0; i < s.planeBuffer.size(); ++i) IntersectPlane(ray, s.planeBuffer[i], (uint32_t)i, hit);
+    for (size_t i = 0; i < s.sphereBuffer.size(); ++i) IntersectSphere(ray, s.sphereBuffer[i], (uint32_t)i, hit);
+    for (size_t i = 0; i < s.cubeBuffer.size(); ++i) IntersectCube(ray, s.cubeBuffer[i], (uint32_t)i, hit);
+    uint32_t firstTriangle = 0;
+    for (size_t i = 0; i < s.customMeshBuffer.size(); ++i) {
+        IntersectCustomMesh(s, ray, s.customMeshBuffer[i], firstTriangle, hit);
+        firstTriangle += (uint32_t)s.customMeshBuffer[i].indicesCount / 3;
+    }
+    if (th.cnt && hit.distance < rt_inf()) th.cnt->hits++;
+    return hit;
+}
+
+// ------------------------------------------------------------------ a7 / a8
+inline float Rand(Thread &th) { return rt_rand(&th.rng); }     // Header.cginc:86-92
+
 
 // Header.cginc:99-108
 Ray CreateRay(f3 origin, f3 direction)
@@ -1135,7 +1284,7 @@ void CSMain(const Scene &s, const RtParams &P, uint32_t idx, uint32_t idy, float
     Ray ray = (P.flags & RT_FLAG_DOF_PRIMARY) ? CreateDoFCameraRay(th, uvx, uvy) : CreateCameraRay(th, uvx, uvy);
     f3 col = rt_splat3(0.0f);
     for (int i = 0; i < RT_MAX_BOUNCE; i++) {
-        const RayHit hit = BVHRayTrace(th, ray);
+        const RayHit hit = (P.flags & RT_FLAG_BRUTE_FORCE) ? BruteForceRayTrace(th, ray) : BVHRayTrace(th, ray);   // :73-77
         const f3 energyBefore = ray.energy;           // ray.energy * Shade(...): left operand read first
         const f3 sh = Shade(th, hit, ray);
         col = rt_add3(col, rt_mul3(energyBefore, sh));
@@ -1193,6 +1342,49 @@ void orc_set_lights(void *h, const RtSphereLight *sl, uint32_t ns, const RtAreaL
     s->areaLights.assign(al, al + na);
     s->discLights.assign(dl, dl + nd);
 }
+// MeshCollector.Init (MeshCollector.cs:170-200)
+void orc_set_primitives(void *h, const RtPlane *planes, uint32_t nPlanes, const RtSphere *spheres, uint32_t nSpheres, const RtCube *cubes,
+                        uint32_t nCubes, const RtCustomMesh *meshes, uint32_t nMeshes, const float *vertices3, const float *normals3,
+                        uint32_t nVertices, const int32_t *indices, uint32_t nIndices)
+{
+    Scene *s = (Scene *)h;
+    s->planeBuffer.assign(planes, planes + nPlanes);
+    s->sphereBuffer.assign(spheres, spheres + nSpheres);
+    s->cubeBuffer.assign(cubes, cubes + nCubes);
+    s->customMeshBuffer.assign(meshes, meshes + nMeshes);
+    s->vertexBuffer.resize(nVertices);
+    s->normalBuffer.resize(nVertices);
+    for (uint32_t i = 0; i < nVertices; ++i) {
+        s->vertexBuffer[i] = ld3(vertices3 + 3 * (size_t)i);
+        s->normalBuffer[i] = ld3(normals3 + 3 * (size_t)i);
+    }
+    s->indexBuffer.assign(indices, indices + nIndices);
+}
+
+// BruteForceRayTrace for caller rays: distance (inf where Shade sees a miss), last writer, normal
+void orc_trace_primitives(void *h, const float *o, const float *d, uint32_t n, float *out_t, uint32_t *out_prim, float *out_normal)
+{
+    const Scene &s = *(Scene *)h;
+    Thread th;
+    th.sc = &s;
+    th.P = nullptr;
+    th.cnt = nullptr;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < (int64_t)n; ++i) {
+        Ray ray;
+        ray.origin = ld3(o + 3 * i);
+        ray.direction = ld3(d + 3 * i);
+        ray.energy = rt_splat3(1.0f);
+        const RayHit hit = BruteForceRayTrace(th, ray);
+        const bool isHit = hit.distance < rt_inf();
+        out_t[i] = isHit ? hit.distance : rt_inf();
+        out_prim[i] = isHit ? hit.triangle : 0xFFFFFFFFu;
+        out_normal[3 * i] = isHit ? hit.normal.x : 0.0f;
+        out_normal[3 * i + 1] = isHit ? hit.normal.y : 0.0f;
+        out_normal[3 * i + 2] = isHit ? hit.normal.z : 0.0f;
+    }
+}
+
 void orc_set_skybox(void *h, const float *faces, uint32_t size)
 {
     Scene *s = (Scene *)h;

@@ -118,6 +118,7 @@ int rt_create(int device_id, RtContext **out_ctx)
     memset(&ctx->params, 0, sizeof ctx->params);
     memset(&ctx->tile, 0, sizeof ctx->tile);
     memset(&ctx->rootBox, 0, sizeof ctx->rootBox);
+    memset(&ctx->brute, 0, sizeof ctx->brute);
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) ctx->numCU = cus;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -147,6 +148,7 @@ int rt_destroy(RtContext *ctx)
     rt_free_build(ctx);
     rt_free_render(ctx);
     rt_free_post(ctx);
+    rt_free_brute(ctx);
     void *ptrs[] = {ctx->dVerts, ctx->dIdx, ctx->dMatIdx, ctx->dShadow, ctx->dMats, ctx->dSphere, ctx->dArea,
                     ctx->dDisc, ctx->dCube, ctx->dStats, ctx->dErrorFlag, ctx->dQCount, ctx->dStackSpill};
     for (void *p : ptrs)
@@ -284,17 +286,21 @@ int rt_set_params(RtContext *ctx, const RtParams *p)
     return RT_OK;
 }
 
-static int ready_to_render(RtContext *ctx)
+// csMain: CSMain will run (needs the BVH, or the primitive lists when the BVH keyword is off);
+// shadowMap: the ShadowMap kernel will run (always walks the BVH, RayTracing.compute:112).
+static int ready_to_render(RtContext *ctx, bool csMain, bool shadowMap)
 {
     if (!ctx->paramsSet) return rt_fail(ctx, RT_E_STATE, "rt_set_params has not been called");
-    if (!ctx->built) return rt_fail(ctx, RT_E_STATE, "rt_bvh_build has not been called");
+    const bool brute = (ctx->params.flags & RT_FLAG_BRUTE_FORCE) != 0;
+    if (csMain && brute && !ctx->bruteSet) return rt_fail(ctx, RT_E_STATE, "RT_FLAG_BRUTE_FORCE is set but rt_primitives_upload has not been called");
+    if (((csMain && !brute) || shadowMap) && !ctx->built) return rt_fail(ctx, RT_E_STATE, "rt_bvh_build has not been called");
     return RT_OK;
 }
 
 int rt_dispatch(RtContext *ctx)
 {
     RT_ENTER(ctx);
-    int rc = ready_to_render(ctx);
+    int rc = ready_to_render(ctx, true, false);
     if (rc) return rc;   // CustomRender returns silently when not initialised (RayTracing.cs:120-121); here it is an error code
     return rt_dispatch_impl(ctx);
 }
@@ -302,7 +308,7 @@ int rt_dispatch(RtContext *ctx)
 int rt_dispatch_shadowmap(RtContext *ctx)
 {
     RT_ENTER(ctx);
-    int rc = ready_to_render(ctx);
+    int rc = ready_to_render(ctx, false, true);
     if (rc) return rc;
     return rt_shadowmap_impl(ctx);
 }
@@ -317,7 +323,7 @@ int rt_accumulate(RtContext *ctx, uint32_t sample_per_pixel, int use_shadow_map)
 int rt_render_frames(RtContext *ctx, const float *seeds, uint32_t n_frames)
 {
     RT_ENTER(ctx);
-    int rc = ready_to_render(ctx);
+    int rc = ready_to_render(ctx, true, ctx->paramsSet && (ctx->params.flags & RT_FLAG_MATTE_MASK) != 0);
     if (rc) return rc;
     if (n_frames && !seeds) return rt_fail(ctx, RT_E_INVALID, "null seeds");
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -15,6 +15,7 @@
 #include "rt_shade.h"
 
 #include "rt_traverse.h"
+#include "rt_brute.h"
 
 // Queue compaction.  A block works through a tile of Q_TILE entries and leaves in
 // stage[] (LDS) the kept slot or RT_INVALID for every entry, in tile order; the
@@ -137,6 +138,39 @@ __global__ __launch_bounds__(PKT_THREADS) void k_traverse_packets(RtSceneView sv
     traverse_packets<COUNT>(sv, src, cursor, lds);
 }
 
+// CSMain's extend step with the BVH keyword off (RayTracing.compute:75-77): one ray per lane,
+// every lane walking the same primitive lists.
+template <class Src>
+__global__ __launch_bounds__(256) void k_brute_extend(RtBruteView bv, Src src)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= src.count()) return;
+    rt_f3 o, d;
+    src.load(i, o, d);
+    src.store(i, brute_force_ray_trace(bv, o, d));
+}
+
+__global__ void k_brute_unpack(RtBruteView bv, const float4 *__restrict__ org, const float4 *__restrict__ dir, const RtHitRec *__restrict__ hits,
+                               uint32_t n, float *t, uint32_t *prim, float *normal3)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const RtHitRec h = hits[i];
+    const bool hitSomething = h.leaf != RT_INVALID;
+    t[i] = hitSomething ? h.t : rt_inf();
+    prim[i] = h.leaf;
+    rt_f3 nrm = rt_splat3(0.0f);
+    if (hitSomething) {
+        DHit hit;
+        const float4 o4 = org[i], d4 = dir[i];
+        brute_load_hit(bv, h, rt_mk3(o4.x, o4.y, o4.z), rt_mk3(d4.x, d4.y, d4.z), hit);
+        nrm = hit.normal;
+    }
+    normal3[3 * i] = nrm.x;
+    normal3[3 * i + 1] = nrm.y;
+    normal3[3 * i + 2] = nrm.z;
+}
+
 __global__ void k_unpack_hits(RtSceneView sv, const RtHitRec *__restrict__ hits, uint32_t n, float *t, uint32_t *tri,
                               float *u, float *v)
 {
@@ -236,8 +270,9 @@ __device__ __forceinline__ void load_hit(const RtSceneView &sv, const RtHitRec &
 // emitter, matte mask, opaque, glass, clear coat) with a counting sort in LDS, so that a wave
 // mostly runs one of those branches instead of all of them.  Paths are independent and carry
 // their own random stream, so the order they are shaded in changes no value.
-template <bool SORT>
-__global__ __launch_bounds__(Q_THREADS) void k_shade(RtSceneView sv, RtTileMap tm, RtParams P, int bounce, const uint32_t *__restrict__ queueIn,
+// BRUTE: the hit records come from k_brute_extend and name a primitive instead of a BVH leaf.
+template <bool SORT, bool BRUTE>
+__global__ __launch_bounds__(Q_THREADS) void k_shade(RtSceneView sv, RtBruteView bv, RtTileMap tm, RtParams P, int bounce, const uint32_t *__restrict__ queueIn,
                                                 const uint32_t *__restrict__ countIn, uint32_t *__restrict__ queueOut,
                                                 uint32_t *__restrict__ countOut, float4 *__restrict__ po,
                                                 float4 *__restrict__ pd, float4 *__restrict__ pe, float4 *__restrict__ rt,
@@ -302,7 +337,8 @@ __global__ __launch_bounds__(Q_THREADS) void k_shade(RtSceneView sv, RtTileMap t
         } else {
             DHit hit;
             int castShadow;
-            load_hit(sv, h, ray.origin, ray.direction, hit, castShadow);
+            if (BRUTE) brute_load_hit(bv, h, ray.origin, ray.direction, hit);
+            else load_hit(sv, h, ray.origin, ray.direction, hit, castShadow);
             if (hit.materialType == 2) {
                 const rt_f3 add = rt_mul3(ray.energy, hit.emissionColor);
                 for (int k = bounce; k < RT_MAX_BOUNCE; ++k) col = rt_add3(col, add);
@@ -627,6 +663,7 @@ static void launch_traverse_packets(RtContext *ctx, const RtSceneView &sv, const
 
 static bool shadow_shares_primary(const RtParams &P)
 {
+    if (P.flags & RT_FLAG_BRUTE_FORCE) return false;   // CSMain's hits are primitives then; the ShadowMap kernel walks the BVH
     // CSMain and ShadowMap draw the same two jitter numbers from the same seed; they trace the
     // same primary ray whenever both use the same camera model (RayTracing.compute:58-65 vs 103-110).
     return ((P.flags & RT_FLAG_DOF_PRIMARY) != 0) == ((P.flags & RT_FLAG_DEPTH_OF_FIELD) != 0);
@@ -674,6 +711,7 @@ static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup
     const uint32_t total = n * frames;
     hipStream_t st = ctx->stream;
     const RtSceneView sv = rt_scene_view(ctx);
+    const bool brute = (ctx->params.flags & RT_FLAG_BRUTE_FORCE) != 0;
     const dim3 blk(Q_THREADS), grid((total + Q_TILE - 1) / Q_TILE);
     RT_HIP(ctx, hipMemsetAsync(ctx->dQCount, 0, CNT_WORDS * sizeof(uint32_t), st));
     rt_timer_begin(ctx, "k_generate");
@@ -688,15 +726,22 @@ static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup
         src.po = ctx->dPo;
         src.pd = ctx->dPd;
         src.hit = ctx->dHit;
-        if (b == 0 && ctx->optPacketPrimary) launch_traverse_packets(ctx, sv, src, ctx->dQCount + CNT_FETCH + b, total, "k_extend");
+        if (brute) {
+            rt_timer_begin(ctx, "k_brute_extend");
+            hipLaunchKernelGGL(k_brute_extend<QueueSrc>, dim3((total + 255) / 256), dim3(256), 0, st, ctx->brute, src);
+            rt_timer_end(ctx);
+        } else if (b == 0 && ctx->optPacketPrimary) launch_traverse_packets(ctx, sv, src, ctx->dQCount + CNT_FETCH + b, total, "k_extend");
         else launch_traverse(ctx, sv, src, ctx->dQCount + CNT_FETCH + b, total, "k_extend");
         if (b == 0 && withShadowSetup) launch_sm_setup(ctx, sv, total, qin, ctx->dQCount);   // before shade moves the rays on
         rt_timer_begin(ctx, "k_shade");
-        if (ctx->optMaterialSort)
-            hipLaunchKernelGGL(k_shade<true>, grid, blk, 0, st, sv, ctx->tile, ctx->params, b, qin, ctx->dQCount + b, qout,
+        if (brute)
+            hipLaunchKernelGGL((k_shade<false, true>), grid, blk, 0, st, sv, ctx->brute, ctx->tile, ctx->params, b, qin, ctx->dQCount + b, qout,
+                               ctx->dQCount + b + 1, ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
+        else if (ctx->optMaterialSort)
+            hipLaunchKernelGGL((k_shade<true, false>), grid, blk, 0, st, sv, ctx->brute, ctx->tile, ctx->params, b, qin, ctx->dQCount + b, qout,
                                ctx->dQCount + b + 1, ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
         else
-            hipLaunchKernelGGL(k_shade<false>, grid, blk, 0, st, sv, ctx->tile, ctx->params, b, qin, ctx->dQCount + b, qout,
+            hipLaunchKernelGGL((k_shade<false, false>), grid, blk, 0, st, sv, ctx->brute, ctx->tile, ctx->params, b, qin, ctx->dQCount + b, qout,
                                ctx->dQCount + b + 1, ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
         rt_timer_end(ctx);
     }
@@ -863,6 +908,25 @@ int rt_trace_device_impl(RtContext *ctx, const float4 *o, const float4 *d, uint3
     if (ctx->optPacketTrace) launch_traverse_packets(ctx, sv, src, ctx->dQCount + CNT_FETCH_TRACE, n, "k_trace");
     else launch_traverse(ctx, sv, src, ctx->dQCount + CNT_FETCH_TRACE, n, "k_trace");
     RT_HIP(ctx, hipGetLastError());
+    return RT_OK;
+}
+
+int rt_trace_primitives_impl(RtContext *ctx, const float4 *o, const float4 *d, uint32_t n, float *t, uint32_t *prim, float *normal3)
+{
+    RtHitRec *hits = nullptr;
+    RT_HIP(ctx, hipMalloc((void **)&hits, (size_t)n * sizeof(RtHitRec)));
+    ArraySrc src;
+    src.org = o;
+    src.dir = d;
+    src.n = n;
+    src.hits = hits;
+    rt_timer_begin(ctx, "k_brute_extend");
+    hipLaunchKernelGGL(k_brute_extend<ArraySrc>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->brute, src);
+    rt_timer_end(ctx);
+    hipLaunchKernelGGL(k_brute_unpack, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->brute, o, d, hits, n, t, prim, normal3);
+    RT_HIP(ctx, hipGetLastError());
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(hits);
     return RT_OK;
 }
 

@@ -85,6 +85,20 @@ struct RtSceneView {
 };
 
 // Tile-local slot -> global pixel mapping (see RtParams in rtcore.h).
+// The brute-force primitive lists (rt_primitives_upload), passed to kernels by value.
+#define RT_PRIM_SHIFT 28
+#define RT_PRIM_INDEX_MASK 0x0FFFFFFFu
+struct RtBruteView {
+    const RtPlane *planes;
+    const RtSphere *spheres;
+    const RtCube *cubes;
+    const RtCustomMesh *meshes;
+    const float4 *triPos;      // 3 per custom-mesh triangle: world-space v0, e1 = v1 - v0, e2 = v2 - v0
+    const float4 *triNrm;      // 3 per triangle: world-space n0, n1, n2
+    const uint32_t *triMesh;   // mesh of each triangle
+    uint32_t nPlanes, nSpheres, nCubes, nMeshes, nTris;
+};
+
 struct RtTileMap {
     int width, height;
     int tileSize, tilesX, tilesY;
@@ -145,6 +159,14 @@ struct RtContext {
     uint32_t nSphere = 0, nArea = 0, nDisc = 0;
     float4 *dCube = nullptr;
     uint32_t cubeSize = 0;
+    RtPlane *dPlanes = nullptr;
+    RtSphere *dSpheres = nullptr;
+    RtCube *dCubes = nullptr;
+    RtCustomMesh *dMeshes = nullptr;
+    float4 *dTriPos = nullptr, *dTriNrm = nullptr;
+    uint32_t *dTriMesh = nullptr;
+    RtBruteView brute;
+    bool bruteSet = false;
 
     // build products
     RtAABB *dTriAABB = nullptr;
@@ -214,6 +236,9 @@ void rt_timer_resolve(RtContext *ctx);
 // api.hip
 float4 *rt_image_ptr(RtContext *ctx, int which);   // tile-local device image behind RT_IMAGE_RT / _CONVERGED / _SHADOWMAP
 
+// brute.hip
+void rt_free_brute(RtContext *ctx);
+
 // post.hip
 void rt_free_post(RtContext *ctx);
 int rt_post_readback_impl(RtContext *ctx, int which, float *dst_rgba);
@@ -234,6 +259,7 @@ int rt_accumulate_impl(RtContext *ctx, uint32_t samplePerPixel, int useShadowMap
 int rt_render_frames_impl(RtContext *ctx, const float *seeds, uint32_t nFrames);
 int rt_trace_device_impl(RtContext *ctx, const float4 *o, const float4 *d, uint32_t n, RtHitRec *hits);
 int rt_expand_local_impl(RtContext *ctx, const float4 *local, float4 *full);
+int rt_trace_primitives_impl(RtContext *ctx, const float4 *o, const float4 *d, uint32_t n, float *t, uint32_t *prim, float *normal3);
 int rt_pack_rays_impl(RtContext *ctx, const float *o3, const float *d3, uint32_t n, float4 *o4, float4 *d4);
 int rt_debug_eval_impl(RtContext *ctx, int which, const float *dx, const float *dy, uint32_t n, float *dout);
 int rt_hits_to_host_impl(RtContext *ctx, const RtHitRec *hits, uint32_t n, float *t, uint32_t *tri, float *u, float *v);

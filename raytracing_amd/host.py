@@ -11,6 +11,7 @@ P/Invoke form of the identical calls.  Mirrored:
   DepthOfField            Assets/Scripts/PostProcess/DepthOfField.cs:22-44  UpdateParameter
   PostProcessStack, ColorCorrection, ColorGrading, Bloom, PostProcessBase   Assets/Scripts/PostProcess/*.cs
   SaveTexture             Assets/Scripts/SaveTexture.cs:15-90          Save (SavePNG)
+  MeshCollector           Assets/Scripts/RayTracing/MeshCollector.cs:16-307   Init, InitPrimitive, InitMaterial
 
 Unity objects (Transform, MeshRenderer, Material, Camera) are replaced by small
 data classes holding just the fields those methods read.
@@ -140,6 +141,82 @@ class BVH:
         self.core.materials_upload(datas)
         if self.onDirty:
             self.onDirty()                       # RayTracing.SetDirty() (BVH.cs:351)
+
+
+# ------------------------------------------------------------------ MeshCollector.cs
+class MeshCollector:
+    """MeshCollector.cs: the brute-force primitive lists of chapters 2-4 (useBVH = false).
+    Each parent is a list of MeshRenderer stand-ins; a plane / sphere / cube is described
+    by its transform alone (MeshCollector.cs:59-66, 84-90, 107-115), a custom mesh by
+    its sharedMesh and localToWorldMatrix (:133-155)."""
+
+    def __init__(self, cam: Camera, planeParent=None, sphereParent=None, cubeParent=None, customMeshParent=None):
+        self.cam = cam
+        self.planeParent, self.sphereParent = planeParent, sphereParent
+        self.cubeParent, self.customMeshParent = cubeParent, customMeshParent
+        self.vertices, self.normals, self.indices = [], [], []
+
+    @staticmethod
+    def InitMaterial(r, rec):                    # :16-40
+        mat = r.sharedMaterial
+        rec["albedo"] = scenes.srgb_to_linear(mat.color[:3]).astype(np.float32)
+        rec["metallic"] = max(0.01, mat._Metallic)
+        rec["smoothness"] = max(0.01, mat._Glossiness)
+        rec["transparent"] = mat.color[3] if int(mat._Mode) == 3 else -1
+        rec["emissionColor"] = mat._EmissionColor[:3] if mat._EMISSION else (0, 0, 0)
+
+    def _plane(self, r, rec):                    # :59-66
+        rec["normal"] = r.transform.up
+        rec["position"] = r.transform.position
+        rec["size"] = r.transform.localScale
+
+    def _sphere(self, r, rec):                   # :84-90
+        rec["center"] = r.transform.position
+        rec["radius"] = np.float32(r.transform.localScale[0]) / np.float32(2)
+
+    def _cube(self, r, rec):                     # :107-115
+        pos = np.asarray(r.transform.position, np.float32)
+        half = np.asarray(r.transform.localScale, np.float32) / np.float32(2)
+        rec["min"], rec["max"] = pos - half, pos + half
+
+    def _custom_mesh(self, r, rec):              # :133-155
+        mesh = r.sharedMesh
+        firstVertex = sum(len(v) for v in self.vertices)
+        self.vertices.append(np.asarray(mesh.positions, np.float32))
+        self.normals.append(np.asarray(mesh.normals, np.float32))
+        firstIndex = sum(len(i) for i in self.indices)
+        cur = np.asarray(mesh.triangles, np.int32).reshape(-1)
+        self.indices.append(cur + np.int32(firstVertex))
+        m = r.transform.matrix if r.transform.matrix is not None else scenes.trs_matrix(
+            r.transform.position, r.transform.rotation, r.transform.localScale)
+        rec["localToWorldMatrix"] = np.asarray(m, np.float32).T.reshape(-1)      # Unity memory order: column-major
+        rec["indicesOffset"], rec["indicesCount"] = firstIndex, len(cur)
+
+    def InitPrimitive(self, parent, dtype, init):           # :271-307
+        rs = [r for r in (parent or []) if r.activeInHierarchy]
+        cam = np.asarray(self.cam.transform.position, np.float64)
+        dist = [float(np.linalg.norm(np.asarray(r.transform.position, np.float64) - cam)) for r in rs]
+        order = sorted(range(len(rs)), key=lambda k: -dist[k])               # OrderByDescending is stable
+        out = np.zeros(len(rs), dtype)
+        for slot, k in enumerate(order):
+            init(rs[k], out[slot:slot + 1])
+            self.InitMaterial(rs[k], out[slot:slot + 1])
+        if len(out) == 0:
+            out = np.zeros(1, dtype)                                          # :299-300  one zeroed element
+        return out
+
+    def Primitives(self):
+        planes = self.InitPrimitive(self.planeParent, wire.PLANE, self._plane)
+        spheres = self.InitPrimitive(self.sphereParent, wire.SPHERE, self._sphere)
+        cubes = self.InitPrimitive(self.cubeParent, wire.CUBE, self._cube)
+        self.vertices, self.normals, self.indices = [], [], []               # :183-185
+        meshes = self.InitPrimitive(self.customMeshParent, wire.CUSTOM_MESH, self._custom_mesh)
+        cat = lambda parts, shape, dt: np.concatenate(parts).astype(dt) if parts else np.zeros(shape, dt)
+        return scenes.Primitives(planes, spheres, cubes, meshes, cat(self.vertices, (0, 3), np.float32),
+                                 cat(self.normals, (0, 3), np.float32), cat(self.indices, 0, np.int32))
+
+    def Init(self, core: RtCore):                # :170-200
+        core.primitives_upload(self.Primitives())
 
 
 # ------------------------------------------------------------------ LightImportanceSampling.cs
@@ -299,9 +376,10 @@ class SaveTexture:
 class RayTracing:
     SamplingType = {"Uniform": 0, "Cosine": 1, "LightImportance": 2, "BSDFImportance": 3, "MultipleImportance": 4}
 
-    def __init__(self, cam: Camera, bvh: BVH, lightImportanceSampling: LightImportanceSampling, width, height,
-                 device_id=0, seed_source=None):
+    def __init__(self, cam: Camera, bvh: Optional[BVH], lightImportanceSampling: LightImportanceSampling, width, height,
+                 device_id=0, seed_source=None, meshCollector: Optional[MeshCollector] = None):
         self.cam, self.bvh, self.lightImportanceSampling = cam, bvh, lightImportanceSampling
+        self.meshCollector = meshCollector
         self.width, self.height = width, height
         self.device_id = device_id
         # public fields of the MonoBehaviour (RayTracing.cs:20-65)
@@ -331,15 +409,16 @@ class RayTracing:
 
     # RayTracing.cs:68-97
     def Start(self):
-        if not self.useBVH:
-            raise NotImplementedError("useBVH = false (brute-force primitives) is outside this library")
         self.core = RtCore(self.device_id)
         self.InitRT()
         self.InitShader()
         self.InitLight()
         self.InitSampling()
-        self.bvh.onDirty = self.SetDirty
-        self.bvh.Init(self.core)
+        if self.useBVH:                          # :84-93
+            self.bvh.onDirty = self.SetDirty
+            self.bvh.Init(self.core)
+        else:
+            self.meshCollector.Init(self.core)
         self.isInitialized = True
 
     def InitRT(self):                            # :172-187
@@ -369,6 +448,8 @@ class RayTracing:
             flags |= wire.FLAG_DEPTH_OF_FIELD
         if self.isRenderMatteMask:
             flags |= wire.FLAG_MATTE_MASK
+        if not self.useBVH:
+            flags |= wire.FLAG_BRUTE_FORCE       # cs.DisableKeyword("BVH")
         p = wire.RtParams()
         p.width, p.height = self.width, self.height
         p.camera2World[:] = self.cam.cameraToWorldMatrix().tolist()

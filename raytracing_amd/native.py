@@ -23,7 +23,7 @@ EXPORTS = [
     "rt_trace_rays_device", "rt_enable_counters", "rt_enable_kernel_timing", "rt_reset_stats", "rt_get_stats",
     "rt_kernel_time", "rt_synchronize", "rt_version", "rt_debug_eval", "rt_set_option",
     "rt_image_upload", "rt_image_size", "rt_post_blit", "rt_post_color_correction", "rt_post_lut_upload",
-    "rt_post_color_grading", "rt_post_bloom", "rt_save_rgb24",
+    "rt_post_color_grading", "rt_post_bloom", "rt_save_rgb24", "rt_primitives_upload", "rt_trace_primitives",
 ]
 
 _lib = None
@@ -112,8 +112,36 @@ class RtCore:
         assert f.ndim == 4 and f.shape[0] == 6 and f.shape[1] == f.shape[2] and f.shape[3] == 4
         self._check(self.lib.rt_skybox_upload(self.ctx, _p(f), C.c_uint32(f.shape[1])))
 
+    def primitives_upload(self, prims):
+        """MeshCollector.Init: `prims` is a scenes.Primitives."""
+        pl = np.ascontiguousarray(prims.planes, wire.PLANE)
+        sp = np.ascontiguousarray(prims.spheres, wire.SPHERE)
+        cu = np.ascontiguousarray(prims.cubes, wire.CUBE)
+        me = np.ascontiguousarray(prims.meshes, wire.CUSTOM_MESH)
+        v = np.ascontiguousarray(prims.vertices, np.float32).reshape(-1, 3)
+        n = np.ascontiguousarray(prims.normals, np.float32).reshape(-1, 3)
+        assert v.shape == n.shape
+        i = np.ascontiguousarray(prims.indices, np.int32)
+        self._check(self.lib.rt_primitives_upload(self.ctx, _p(pl), C.c_uint32(len(pl)), _p(sp), C.c_uint32(len(sp)), _p(cu),
+                                                  C.c_uint32(len(cu)), _p(me), C.c_uint32(len(me)), _p(v), _p(n),
+                                                  C.c_uint32(len(v)), _p(i), C.c_uint32(len(i))))
+
+    def trace_primitives(self, origins, directions):
+        o = np.ascontiguousarray(origins, np.float32)
+        d = np.ascontiguousarray(directions, np.float32)
+        n = len(o)
+        t, prim, nrm = np.zeros(n, np.float32), np.zeros(n, np.uint32), np.zeros((n, 3), np.float32)
+        self._check(self.lib.rt_trace_primitives(self.ctx, _p(o), _p(d), C.c_uint32(n), _p(t), _p(prim), _p(nrm)))
+        return dict(t=t, primitive=prim, normal=nrm)
+
     def upload(self, scene):
-        """Everything BVH.Init + LightImportanceSampling.Init + InitShader upload."""
+        """Everything BVH.Init (or MeshCollector.Init) + LightImportanceSampling.Init + InitShader upload."""
+        if scene.primitives is not None:
+            self.primitives_upload(scene.primitives)
+        if scene.n_triangles == 0 and scene.primitives is not None:
+            self.lights_upload(scene.sphere_lights, scene.area_lights, scene.disc_lights)
+            self.skybox_upload(scene.skybox)
+            return
         self.scene_upload(scene.vertices, scene.indices, scene.material_index, scene.shadow_index)
         self.materials_upload(scene.materials)
         self.lights_upload(scene.sphere_lights, scene.area_lights, scene.disc_lights)

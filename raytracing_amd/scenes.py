@@ -168,6 +168,17 @@ def quat_mul(a, b):
 IDENTITY_Q = (0.0, 0.0, 0.0, 1.0)
 
 
+def trs_matrix(position, rotation=IDENTITY_Q, scale=(1, 1, 1)):
+    """Matrix4x4.TRS as a 4x4 array (row r, column c)."""
+    m = np.eye(4)
+    for c in range(3):
+        e = np.zeros(3)
+        e[c] = scale[c]
+        m[:3, c] = quat_rotate(rotation, e)
+    m[:3, 3] = position
+    return m
+
+
 # ----------------------------------------------------------------- materials
 def srgb_to_linear(c):
     """UnityEngine.Color.linear."""
@@ -199,6 +210,22 @@ def material_data(color=(1, 1, 1, 1), metallic=0.0, glossiness=0.5, mode=0, emis
 
 # ----------------------------------------------------------------- scene container
 @dataclass
+class Primitives:
+    """The buffers MeshCollector.Init uploads (MeshCollector.cs:170-200)."""
+    planes: np.ndarray = field(default_factory=lambda: np.zeros(0, wire.PLANE))
+    spheres: np.ndarray = field(default_factory=lambda: np.zeros(0, wire.SPHERE))
+    cubes: np.ndarray = field(default_factory=lambda: np.zeros(0, wire.CUBE))
+    meshes: np.ndarray = field(default_factory=lambda: np.zeros(0, wire.CUSTOM_MESH))
+    vertices: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), F32))
+    normals: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), F32))
+    indices: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+
+    @property
+    def n_triangles(self):
+        return int(self.meshes["indicesCount"].sum()) // 3 if len(self.meshes) else 0
+
+
+@dataclass
 class Scene:
     name: str
     vertices: np.ndarray          # MESH_VERTEX[V]
@@ -212,6 +239,7 @@ class Scene:
     skybox: np.ndarray = None     # f32[6,S,S,4] or None
     params: wire.RtParams = None
     notes: str = ""
+    primitives: Primitives = None  # brute-force lists (useBVH = false), or None
 
     @property
     def n_triangles(self):
@@ -484,6 +512,72 @@ def car_standin(width=1920, height=1080, detail=1.0, sampling=wire.SAMPLING_MIS,
                              lens_radius=0.3 if dof else 0.0, focal_length=focal if dof else 1.0,
                              shadow_intensity=0.8)
     return scn
+
+
+def _surface(rec, color, metallic, glossiness):
+    rec["albedo"] = srgb_to_linear(color[:3]).astype(F32)
+    rec["metallic"], rec["smoothness"], rec["transparent"] = max(0.01, metallic), max(0.01, glossiness), -1
+    rec["emissionColor"] = 0
+
+
+def primitive_room(width=256, height=256, sampling=wire.SAMPLING_MIS, mesh_segments=12, seed=3):
+    """A chapter-3/4 style scene for the brute-force path (useBVH = false): a floor and a
+    back wall (planes), a row of spheres of varying metallic / smoothness, a few cubes and two
+    custom meshes (a tessellated sphere under a non-uniform TRS and a tilted box), lit by one
+    area light, one sphere light and the procedural sky.  Lists are in far-to-near order as
+    MeshCollector.InitPrimitive sorts them."""
+    cam = np.array([0.0, 2.0, -9.0])
+    rng = np.random.default_rng(seed)
+    planes = np.zeros(2, wire.PLANE)
+    planes[0]["normal"], planes[0]["position"], planes[0]["size"] = (0, 0, -1), (0, 3, 6), (16, 8, 1)
+    _surface(planes[0:1], (0.55, 0.6, 0.7, 1), 0.0, 0.3)
+    planes[1]["normal"], planes[1]["position"], planes[1]["size"] = (0, 1, 0), (0, 0, 0), (16, 1, 16)
+    _surface(planes[1:2], (0.7, 0.7, 0.7, 1), 0.0, 0.5)
+    spheres = np.zeros(5, wire.SPHERE)
+    for k in range(5):
+        spheres[k]["center"], spheres[k]["radius"] = (-4 + 2 * k, 0.8, 1.5 + 0.3 * k), 0.8
+        _surface(spheres[k:k + 1], (0.9, 0.3 + 0.1 * k, 0.2, 1), k / 4, 0.2 + 0.2 * k)
+    cubes = np.zeros(3, wire.CUBE)
+    for k in range(3):
+        c = np.array([-3 + 3 * k, 0.5, -1.5])
+        cubes[k]["min"], cubes[k]["max"] = c - 0.5, c + 0.5
+        _surface(cubes[k:k + 1], (0.2, 0.5 + 0.2 * k, 0.9, 1), 0.1, 0.6)
+    order = lambda a, key: a[np.argsort(-np.linalg.norm(a[key] - cam, axis=1), kind="stable")]
+    planes, spheres = order(planes, "position"), order(spheres, "center")
+    cubes = cubes[np.argsort(-np.linalg.norm((cubes["min"] + cubes["max"]) / 2 - cam, axis=1), kind="stable")]
+    ball, box = uv_sphere_mesh(mesh_segments, max(mesh_segments // 2, 2)), box_mesh()
+    meshes = np.zeros(2, wire.CUSTOM_MESH)
+    verts = np.concatenate([ball.positions, box.positions]).astype(F32)
+    norms = np.concatenate([ball.normals, box.normals]).astype(F32)
+    idx = np.concatenate([ball.triangles.reshape(-1), box.triangles.reshape(-1) + len(ball.positions)]).astype(np.int32)
+    m0 = trs_matrix((1.0, 2.6, 2.0), quat_from_euler_deg(20, 30, 0), (1.4, 0.7, 1.0))
+    m1 = trs_matrix((-2.5, 2.2, 3.0), quat_from_euler_deg(25, 40, 10), (1.2, 1.2, 1.2))
+    meshes[0]["localToWorldMatrix"], meshes[1]["localToWorldMatrix"] = m0.T.reshape(-1), m1.T.reshape(-1)
+    meshes[0]["indicesOffset"], meshes[0]["indicesCount"] = 0, ball.triangles.size
+    meshes[1]["indicesOffset"], meshes[1]["indicesCount"] = ball.triangles.size, box.triangles.size
+    _surface(meshes[0:1], (0.9, 0.8, 0.3, 1), 0.8, 0.7)
+    _surface(meshes[1:2], (0.4, 0.8, 0.4, 1), 0.0, 0.4)
+    del rng
+    prims = Primitives(planes, spheres, cubes, meshes, verts, norms, idx)
+    sc = Scene("primitive_room", np.zeros(0, wire.MESH_VERTEX), np.zeros(0, np.uint32), np.zeros(0, np.uint32),
+               np.zeros((0, 2), np.int32), np.zeros(0, wire.MATERIAL), primitives=prims)
+    sc.area_lights = np.array([area_light((0, 6.5, 1.0), quat_from_euler_deg(90, 0, 0), (1, 1), (4, 4, 1))], wire.AREA_LIGHT)
+    sc.sphere_lights = np.array([sphere_light((-5, 5, -2), 0.5, 1.2)], wire.SPHERE_LIGHT)
+    sc.skybox = procedural_skybox(32)
+    sc.params = make_params(width, height, cam, quat_from_euler_deg(5, 0, 0), fov=50.0, sampling=sampling,
+                            flags=wire.FLAG_BRUTE_FORCE, sky_intensity=2.0)
+    return sc
+
+
+def primitive_rays(n, seed=11):
+    """Rays for first-hit checks of the primitive room: origins around the camera side, aimed into the room,
+    plus some from inside / behind the primitives (exercise the unconditional sphere and cube writes)."""
+    rng = np.random.default_rng(seed)
+    o = np.stack([rng.uniform(-7, 7, n), rng.uniform(0.2, 6, n), rng.uniform(-9, 5, n)], 1)
+    target = np.stack([rng.uniform(-6, 6, n), rng.uniform(0, 4, n), rng.uniform(-2, 6, n)], 1)
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o.astype(F32), d.astype(F32)
 
 
 def triangle_soup(n_triangles, seed=5, width=256, height=256, extent=100.0, edge=0.5):

@@ -31,6 +31,15 @@ SPHERE_LIGHT = np.dtype([("position", "<f4", 3), ("radius", "<f4")])
 AREA_LIGHT = np.dtype([("position", "<f4", 3), ("normal", "<f4", 3), ("up", "<f4", 3), ("size", "<f4", 2)])
 DISC_LIGHT = np.dtype([("position", "<f4", 3), ("normal", "<f4", 3), ("radius", "<f4")])
 
+# BruteForceRayTracing.cginc:5-65 = MeshCollector.cs:46-156
+_SURFACE = [("albedo", "<f4", 3), ("metallic", "<f4"), ("smoothness", "<f4"), ("transparent", "<f4"), ("emissionColor", "<f4", 3)]
+PLANE = np.dtype([("normal", "<f4", 3), ("position", "<f4", 3), ("size", "<f4", 3)] + _SURFACE)
+SPHERE = np.dtype([("center", "<f4", 3), ("radius", "<f4")] + _SURFACE)
+CUBE = np.dtype([("min", "<f4", 3), ("max", "<f4", 3)] + _SURFACE)
+CUSTOM_MESH = np.dtype([("localToWorldMatrix", "<f4", 16), ("indicesOffset", "<i4"), ("indicesCount", "<i4")] + _SURFACE)
+assert PLANE.itemsize == 72 and SPHERE.itemsize == 52 and CUBE.itemsize == 60 and CUSTOM_MESH.itemsize == 108
+PRIM_PLANE, PRIM_SPHERE, PRIM_CUBE, PRIM_TRIANGLE = 0, 1, 2, 3
+
 assert AABB.itemsize == 32 and TRIANGLE.itemsize == 192          # MeshBufferContainer.cs:54-62
 assert INTERNAL_NODE.itemsize == 24 and LEAF_NODE.itemsize == 8
 assert MATERIAL.itemsize == 56 and MESH_VERTEX.itemsize == 44
@@ -43,6 +52,7 @@ SAMPLING_UNIFORM, SAMPLING_COSINE, SAMPLING_LIGHT, SAMPLING_BSDF, SAMPLING_MIS =
 FLAG_DEPTH_OF_FIELD = 0x10
 FLAG_DOF_PRIMARY = 0x20
 FLAG_MATTE_MASK = 0x40
+FLAG_BRUTE_FORCE = 0x80
 
 IMAGE_RT, IMAGE_CONVERGED, IMAGE_SHADOWMAP, IMAGE_POSTPROCESS, IMAGE_USER = 0, 1, 2, 3, 4
 WRAP_CLAMP, WRAP_REPEAT = 0, 1
