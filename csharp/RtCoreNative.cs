@@ -16,7 +16,7 @@ public static class RtCoreNative
     const string Lib = "rtcore";
 
     public const int RT_OK = 0, RT_E_INVALID = -1, RT_E_DEVICE = -2, RT_E_NOMEM = -3, RT_E_STATE = -4, RT_E_OVERFLOW = -5;
-    public const uint RT_FLAG_DEPTH_OF_FIELD = 0x10, RT_FLAG_DOF_PRIMARY = 0x20, RT_FLAG_MATTE_MASK = 0x40;
+    public const uint RT_FLAG_DEPTH_OF_FIELD = 0x10, RT_FLAG_DOF_PRIMARY = 0x20, RT_FLAG_MATTE_MASK = 0x40, RT_FLAG_BRUTE_FORCE = 0x80;
     public const int RT_IMAGE_RT = 0, RT_IMAGE_CONVERGED = 1, RT_IMAGE_SHADOWMAP = 2, RT_IMAGE_POSTPROCESS = 3, RT_IMAGE_USER = 4;
     public const int RT_WRAP_CLAMP = 0, RT_WRAP_REPEAT = 1;
 
@@ -86,6 +86,13 @@ public static class RtCoreNative
     [DllImport(Lib)] public static extern int rt_upload_converged(IntPtr ctx, Color[] srcRgba, uint samplePerPixel);
     [DllImport(Lib)] public static extern int rt_get_stats(IntPtr ctx, out RtStats stats);
     [DllImport(Lib)] public static extern int rt_set_option(IntPtr ctx, int option, int value);
+
+    // brute-force primitives (useBVH = false): T = the host's own Plane / Sphere / Cube / CustomMesh structs (MeshCollector.cs:46-156)
+    [DllImport(Lib)] public static extern int rt_primitives_upload(IntPtr ctx, Array planes, uint nPlanes, Array spheres, uint nSpheres, Array cubes, uint nCubes,
+                                                                   Array customMeshes, uint nMeshes, Vector3[] vertices, Vector3[] normals, uint nVertices,
+                                                                   int[] indices, uint nIndices);
+    [DllImport(Lib)] public static extern int rt_trace_primitives(IntPtr ctx, Vector3[] origins, Vector3[] directions, uint n, float[] outT, uint[] outPrimitive,
+                                                                  Vector3[] outNormal);
 
     // post-process chain: the destination is always RT_IMAGE_POSTPROCESS (RayTracing.postProcessRT)
     [DllImport(Lib)] public static extern int rt_image_upload(IntPtr ctx, Color[] rgba, int width, int height);

@@ -286,7 +286,11 @@ int rt_trace_rays_device(RtContext *ctx, const void *device_origins4, const void
 /* Numeric self-check: evaluates one of the shared numeric rules of rt_math.h on
  * the device for n host inputs (which: 0 sin, 1 cos, 2 acos, 3 pow(x,y),
  * 4 sRGB->linear, 5 linear->sRGB, 6 float->uint as bits, 7 the Rand() stream of
- * pixel (x[0],x[1]) with seed y[0], Header.cginc:79-92).  No reference counterpart. */
+ * pixel (x[0],x[1]) with seed y[0], Header.cginc:79-92; 8 DiscLightImportanceSampling,
+ * ImportanceSampling.cginc:147-160 -- a function the reference defines but never calls --
+ * for x = pixel(2), hit.position(3), hit.normal(3), hit.albedo(3), light.position(3),
+ * light.radius and y[0] = seed, giving n <= 10 values: ray.origin, ray.direction, func, pdf).
+ * No reference counterpart. */
 int rt_debug_eval(RtContext *ctx, int which, const float *x, const float *y, uint32_t n, float *out);
 
 /* ------------------------------------------------------ post-process chain */

@@ -163,6 +163,14 @@ def rand_sequence(px, py, seed, n):
     return out, st
 
 
+def disc_light(x15, seed):
+    """DiscLightImportanceSampling for one hit / light / pixel -> origin(3), direction(3), func(3), pdf."""
+    x = np.ascontiguousarray(x15, np.float32)
+    out = np.zeros(10, np.float32)
+    lib().orc_disc_light(_p(x), C.c_float(seed), _p(out))
+    return out
+
+
 def math(which, x, y=None):
     x = np.ascontiguousarray(x, np.float32)
     y = x if y is None else np.ascontiguousarray(y, np.float32)

@@ -973,6 +973,18 @@ void SphereLightImportanceSampling(Thread &th, const RayHit &hit, Ray &ray, cons
     func = rt_scale3(rt_divs3(hit.albedo, RT_PI), rt_saturate(rt_dot3(hit.normal, ray.direction)));
 }
 
+// :147-160 (never called by the reference: _LightImportanceSampling has no disc branch)
+void DiscLightImportanceSampling(Thread &th, const RayHit &hit, Ray &ray, const RtDiscLight &light, f3 &func, float &pdf)
+{
+    const float theta = rt_sqrt(Rand(th) * light.radius);
+    const float phi = TWO_PI * Rand(th);
+    const f3 direction = rt_normalize3(rt_sub3(ld3(light.position), hit.position));
+    ray.origin = rt_add3(hit.position, rt_scale3(hit.normal, RT_NORMAL_BIAS));
+    ray.direction = Tangent2World(theta, phi, direction);
+    func = rt_scale3(rt_divs3(hit.albedo, RT_PI), rt_saturate(rt_dot3(hit.normal, ray.direction)));
+    pdf = 1 / (RT_PI * light.radius * light.radius);
+}
+
 // :122-143
 void AreaLightImportanceSampling(Thread &th, const RayHit &hit, Ray &ray, const RtAreaLight &light, f3 &func, float &pdf)
 {
@@ -1601,6 +1613,31 @@ void orc_rand_sequence(uint32_t px, uint32_t py, float seed, uint32_t n, float *
         out[i] = rt_rand(&r);
         if (out_state) out_state[i] = r.state;
     }
+}
+// x = pixel(2), hit.position(3), hit.normal(3), hit.albedo(3), light.position(3), light.radius; out = origin, direction, func, pdf
+void orc_disc_light(const float *x, float seed, float *out)
+{
+    Thread th;
+    th.sc = nullptr;
+    th.P = nullptr;
+    th.cnt = nullptr;
+    rt_rng_init(&th.rng, (uint32_t)x[0], (uint32_t)x[1], seed);
+    RayHit hit = CreateRayHit();
+    hit.position = ld3(x + 2);
+    hit.normal = ld3(x + 5);
+    hit.albedo = ld3(x + 8);
+    RtDiscLight light;
+    memset(&light, 0, sizeof light);
+    memcpy(light.position, x + 11, 12);
+    light.radius = x[14];
+    Ray ray;
+    ray.origin = ray.direction = rt_splat3(0.0f);
+    ray.energy = rt_splat3(1.0f);
+    f3 func;
+    float pdf;
+    DiscLightImportanceSampling(th, hit, ray, light, func, pdf);
+    const float o[10] = {ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x, ray.direction.y, ray.direction.z, func.x, func.y, func.z, pdf};
+    memcpy(out, o, sizeof o);
 }
 // which: 0 sin, 1 cos, 2 acos, 3 pow(x,y), 4 srgb->linear, 5 linear->srgb, 6 ftou (as float bits of the uint)
 void orc_math(int which, const float *x, const float *y, uint32_t n, float *out)

@@ -488,13 +488,13 @@ int rt_debug_eval(RtContext *ctx, int which, const float *x, const float *y, uin
 {
     RT_ENTER(ctx);
     if (!x || !y || !out || n == 0) return rt_fail(ctx, RT_E_INVALID, "bad rt_debug_eval arguments");
-    const uint32_t nin = which == 7 ? 2u : n;
+    const uint32_t nin = which == 7 ? 2u : (which == 8 ? 15u : n);
     float *dx = nullptr, *dy = nullptr, *dout = nullptr;
     RT_HIP(ctx, hipMalloc((void **)&dx, (size_t)nin * 4));
     RT_HIP(ctx, hipMalloc((void **)&dy, (size_t)nin * 4));
     RT_HIP(ctx, hipMalloc((void **)&dout, (size_t)n * 4));
     RT_HIP(ctx, hipMemcpyAsync(dx, x, (size_t)nin * 4, hipMemcpyHostToDevice, ctx->stream));
-    RT_HIP(ctx, hipMemcpyAsync(dy, y, (size_t)(which == 7 ? 1 : nin) * 4, hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipMemcpyAsync(dy, y, (size_t)(which == 7 || which == 8 ? 1 : nin) * 4, hipMemcpyHostToDevice, ctx->stream));
     int rc = rt_debug_eval_impl(ctx, which, dx, dy, n, dout);
     if (rc) return rc;
     RT_HIP(ctx, hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));

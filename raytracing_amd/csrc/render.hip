@@ -140,14 +140,27 @@ __global__ __launch_bounds__(PKT_THREADS) void k_traverse_packets(RtSceneView sv
 
 // CSMain's extend step with the BVH keyword off (RayTracing.compute:75-77): one ray per lane,
 // every lane walking the same primitive lists.
+// stats: the context's counter block when counters are on (rays -> [0], hits -> [4]), else null.
 template <class Src>
-__global__ __launch_bounds__(256) void k_brute_extend(RtBruteView bv, Src src)
+__global__ __launch_bounds__(256) void k_brute_extend(RtBruteView bv, Src src, unsigned long long *__restrict__ stats)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= src.count()) return;
-    rt_f3 o, d;
-    src.load(i, o, d);
-    src.store(i, brute_force_ray_trace(bv, o, d));
+    const bool live = i < src.count();
+    bool hitSomething = false;
+    if (live) {
+        rt_f3 o, d;
+        src.load(i, o, d);
+        const RtHitRec h = brute_force_ray_trace(bv, o, d);
+        hitSomething = h.leaf != RT_INVALID;
+        src.store(i, h);
+    }
+    if (stats) {
+        const uint32_t rays = (uint32_t)__popcll(__ballot(live)), hits = (uint32_t)__popcll(__ballot(hitSomething));
+        if ((threadIdx.x & 63u) == 0 && rays) {
+            atomicAdd(&stats[0], (unsigned long long)rays);
+            if (hits) atomicAdd(&stats[4], (unsigned long long)hits);
+        }
+    }
 }
 
 __global__ void k_brute_unpack(RtBruteView bv, const float4 *__restrict__ org, const float4 *__restrict__ dir, const RtHitRec *__restrict__ hits,
@@ -493,6 +506,26 @@ __global__ void k_debug_eval(int which, const float *__restrict__ x, const float
         for (uint32_t k = 0; k < n; ++k) out[k] = rt_rand(&r);
         return;
     }
+    if (which == 8) {          // DiscLightImportanceSampling: x = pixel(2) hit.position(3) hit.normal(3) hit.albedo(3) light.position(3) radius
+        if (i != 0) return;    // y[0] = seed; out = ray.origin(3) ray.direction(3) func(3) pdf
+        DShadeCtx c;
+        c.sv = nullptr;
+        c.P = nullptr;
+        rt_rng_init(&c.rng, (uint32_t)x[0], (uint32_t)x[1], y[0]);
+        DHit hit;
+        hit.position = rt_mk3(x[2], x[3], x[4]);
+        hit.normal = rt_mk3(x[5], x[6], x[7]);
+        hit.albedo = rt_mk3(x[8], x[9], x[10]);
+        DRay ray;
+        ray.origin = ray.direction = rt_splat3(0.0f);
+        ray.energy = rt_splat3(1.0f);
+        rt_f3 func;
+        float pdf;
+        d_disc_light(c, hit, ray, rt_mk3(x[11], x[12], x[13]), x[14], func, pdf);
+        const float o[10] = {ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x, ray.direction.y, ray.direction.z, func.x, func.y, func.z, pdf};
+        for (uint32_t k = 0; k < n && k < 10; ++k) out[k] = o[k];
+        return;
+    }
     if (i >= n) return;
     switch (which) {
     case 0: out[i] = rt_sin(x[i]); break;
@@ -728,7 +761,7 @@ static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup
         src.hit = ctx->dHit;
         if (brute) {
             rt_timer_begin(ctx, "k_brute_extend");
-            hipLaunchKernelGGL(k_brute_extend<QueueSrc>, dim3((total + 255) / 256), dim3(256), 0, st, ctx->brute, src);
+            hipLaunchKernelGGL(k_brute_extend<QueueSrc>, dim3((total + 255) / 256), dim3(256), 0, st, ctx->brute, src, ctx->countersOn ? ctx->dStats : nullptr);
             rt_timer_end(ctx);
         } else if (b == 0 && ctx->optPacketPrimary) launch_traverse_packets(ctx, sv, src, ctx->dQCount + CNT_FETCH + b, total, "k_extend");
         else launch_traverse(ctx, sv, src, ctx->dQCount + CNT_FETCH + b, total, "k_extend");
@@ -921,7 +954,7 @@ int rt_trace_primitives_impl(RtContext *ctx, const float4 *o, const float4 *d, u
     src.n = n;
     src.hits = hits;
     rt_timer_begin(ctx, "k_brute_extend");
-    hipLaunchKernelGGL(k_brute_extend<ArraySrc>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->brute, src);
+    hipLaunchKernelGGL(k_brute_extend<ArraySrc>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->brute, src, ctx->countersOn ? ctx->dStats : nullptr);
     rt_timer_end(ctx);
     hipLaunchKernelGGL(k_brute_unpack, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->brute, o, d, hits, n, t, prim, normal3);
     RT_HIP(ctx, hipGetLastError());

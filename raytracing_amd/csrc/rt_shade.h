@@ -176,6 +176,20 @@ RTD void d_sphere_light(DShadeCtx &c, const DHit &hit, DRay &ray, f3 lpos, float
     func = rt_scale3(rt_divs3(hit.albedo, RT_PI), rt_saturate(rt_dot3(hit.normal, ray.direction)));
 }
 
+// ImportanceSampling.cginc:147-160.  Defined by the reference but never called:
+// _LightImportanceSampling (:163-181) has no DISC_LIGHT branch, so uploaded disc lights
+// light nothing.  Kept callable for the numeric self-check (rt_debug_eval 8).
+RTD void d_disc_light(DShadeCtx &c, const DHit &hit, DRay &ray, f3 lpos, float lradius, f3 &func, float &pdf)
+{
+    const float theta = rt_sqrt(d_rand(c) * lradius);
+    const float phi = D_TWO_PI * d_rand(c);
+    const f3 direction = rt_normalize3(rt_sub3(lpos, hit.position));
+    ray.origin = d_offset_origin(hit);
+    ray.direction = d_tangent2world(theta, phi, direction);
+    func = rt_scale3(rt_divs3(hit.albedo, RT_PI), rt_saturate(rt_dot3(hit.normal, ray.direction)));
+    pdf = 1 / (RT_PI * lradius * lradius);
+}
+
 // ImportanceSampling.cginc:122-143
 RTD void d_area_light(DShadeCtx &c, const DHit &hit, DRay &ray, f3 lpos, f3 lnormal, f3 lup, float sx, float sy, f3 &func,
                       float &pdf)

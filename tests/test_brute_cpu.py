@@ -142,3 +142,23 @@ def test_mesh_collector_merges_custom_meshes_and_a_zeroed_pad_never_hits():
     r = oracle_py.Oracle(sc).trace_primitives(o, d)
     assert r["primitive"][0] >> 28 == wire.PRIM_TRIANGLE and abs(r["t"][0] - 9.0) < 1e-5
     assert r["primitive"][1] == INVALID                                                # the padded zero plane / sphere / cube stay silent here
+
+
+# ---------------------------------------------------------------- disc lights
+def test_disc_light_function_restated_but_never_used():
+    """DiscLightImportanceSampling (ImportanceSampling.cginc:147-160) is defined and its lights are
+    uploaded (LightImportanceSampling.cs:94-106), but _LightImportanceSampling never calls it."""
+    x = np.array([7, 3, 0.5, 1.0, -2.0, 0, 1, 0, 0.8, 0.6, 0.4, 1.0, 6.0, -1.0, 0.75], np.float32)
+    out = oracle_py.disc_light(x, 0.25)
+    np.testing.assert_allclose(out[:3], x[2:5] + x[5:8] * np.float32(0.001), rtol=0, atol=1e-7)
+    assert abs(np.linalg.norm(out[3:6]) - 1) < 1e-5
+    assert abs(out[9] - 1 / (np.pi * 0.75 ** 2)) < 1e-6
+    np.testing.assert_allclose(out[6:9], x[8:11] / np.pi * max(float(out[3:6] @ x[5:8]), 0.0), rtol=1e-5)
+    # a scene's disc lights change no pixel
+    sc = scenes.cornell_box(24, 24, sphere_segments=8, sampling=wire.SAMPLING_LIGHT)
+    a = oracle_py.Oracle(sc).build().render(sc.params)
+    d = np.zeros(1, wire.DISC_LIGHT)
+    d[0]["position"], d[0]["normal"], d[0]["radius"] = (0, 10, 0), (0, -1, 0), 3.0
+    sc.disc_lights = d
+    b = oracle_py.Oracle(sc).build().render(sc.params)
+    assert a.tobytes() == b.tobytes()

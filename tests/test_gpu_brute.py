@@ -102,3 +102,29 @@ def test_brute_errors():
             c.dispatch_shadowmap()                         # the ShadowMap kernel needs the BVH
     finally:
         c.close()
+
+
+def test_disc_light_function_bit_exact_and_disc_lights_change_nothing(core):
+    rng = np.random.default_rng(3)
+    for k in range(16):
+        n = rng.normal(size=3)
+        x = np.concatenate([[rng.integers(0, 1920), rng.integers(0, 1080)], rng.uniform(-5, 5, 3), n / np.linalg.norm(n),
+                            rng.uniform(0, 1, 3), rng.uniform(-8, 8, 3), [rng.uniform(0.05, 3)]]).astype(np.float32)
+        seed = float(np.float32(rng.random()))
+        got = core.debug_eval(8, x, np.array([seed], np.float32), n=10)
+        H.assert_bits_equal(got, oracle_py.disc_light(x, seed), f"DiscLightImportanceSampling case {k}")
+    sc = scenes.cornell_box(48, 48, sphere_segments=8, sampling=wire.SAMPLING_MIS)
+    seeds = scenes.frame_seeds(2, seed=3)
+    imgs = []
+    for with_disc in (False, True):
+        if with_disc:
+            d = np.zeros(2, wire.DISC_LIGHT)
+            d["position"], d["normal"], d["radius"] = (0, 10, 0), (0, -1, 0), 3.0
+            sc.disc_lights = d
+        core.upload(sc)
+        core.bvh_build()
+        core.set_params(sc.params)
+        core.set_dirty()
+        core.render_frames(seeds)
+        imgs.append(core.readback(wire.IMAGE_CONVERGED))
+    assert imgs[0].tobytes() == imgs[1].tobytes()
