@@ -312,43 +312,56 @@ def load_scene(scene_path: str, project_root: str, width=256, height=256, device
     bvh_node, bvh_kind = ref(rt_body, "bvh")
     bvh_body = bvh_node.components[bvh_kind] if bvh_node else {}
     mesh_parent = nodes.get((bvh_body.get("meshParent") or {}).get("fileID", 0))
-    renderers: List[host.MeshRenderer] = []
     mesh_cache: Dict[tuple, scenes.Mesh] = {}
-    for n in ([mesh_parent] + list(mesh_parent.descendants())) if mesh_parent else []:
-        mesh, material, enabled, cast, receive = None, None, True, True, True
-        if "#model_mesh" in n.components:
-            mesh, material = n.components["#model_mesh"], n.components["#model_material"]
-        elif "MeshFilter" in n.components and "MeshRenderer" in n.components:
-            mf, mr = n.components["MeshFilter"], n.components["MeshRenderer"]
-            mref = mf.get("m_Mesh") or {}
-            key = (mref.get("guid"), mref.get("fileID"))
-            try:
-                if key not in mesh_cache:
-                    if key[0] == BUILTIN_GUID:
-                        mesh_cache[key] = unity_builtin_mesh(BUILTIN_MESH.get(key[1], str(key[1])))
-                        if BUILTIN_MESH.get(key[1]) == "Sphere":
-                            warnings.append("built-in Sphere approximated by a 24 x 16 UV sphere")
-                    else:
-                        ms = proj.model_meshes(key[0])
-                        m0 = ms[0]
-                        mesh_cache[key] = scenes.Mesh(m0.positions, m0.normals, np.zeros_like(m0.positions), m0.uvs,
-                                                      m0.triangles.astype(np.int32))
-                mesh = mesh_cache[key]
-            except (FileNotFoundError, NotImplementedError, ValueError) as e:
-                warnings.append(f"{n.name}: {e}")
-                continue
-            mats = mr.get("m_Materials") or [{}]
-            material = proj.material(mats[0].get("guid")) if mats and mats[0].get("guid") else host.Material()
-            enabled = bool(mr.get("m_Enabled", 1))
-            cast = int(mr.get("m_CastShadows", 1)) == 1            # ShadowCastingMode.On
-            receive = bool(mr.get("m_ReceiveShadows", 1))
-        if mesh is None:
-            continue
-        t = host.Transform()
-        t.matrix = n.local_to_world()
-        renderers.append(host.MeshRenderer(mesh, material, t, enabled=enabled, activeInHierarchy=n.active_in_hierarchy(),
-                                           shadowCastingOn=cast, receiveShadows=receive))
-        renderers[-1].name = n.name
+
+    def renderers_under(parent) -> List[host.MeshRenderer]:
+      """GetComponentsInChildren<MeshRenderer / Renderer>: the parent itself and everything below it."""
+      renderers: List[host.MeshRenderer] = []
+      for n in ([parent] + list(parent.descendants())) if parent else []:
+          mesh, material, enabled, cast, receive = None, None, True, True, True
+          if "#model_mesh" in n.components:
+              mesh, material = n.components["#model_mesh"], n.components["#model_material"]
+          elif "MeshFilter" in n.components and "MeshRenderer" in n.components:
+              mf, mr = n.components["MeshFilter"], n.components["MeshRenderer"]
+              mref = mf.get("m_Mesh") or {}
+              key = (mref.get("guid"), mref.get("fileID"))
+              try:
+                  if key not in mesh_cache:
+                      if key[0] == BUILTIN_GUID:
+                          mesh_cache[key] = unity_builtin_mesh(BUILTIN_MESH.get(key[1], str(key[1])))
+                          if BUILTIN_MESH.get(key[1]) == "Sphere":
+                              warnings.append("built-in Sphere approximated by a 24 x 16 UV sphere")
+                      else:
+                          ms = proj.model_meshes(key[0])
+                          m0 = ms[0]
+                          mesh_cache[key] = scenes.Mesh(m0.positions, m0.normals, np.zeros_like(m0.positions), m0.uvs,
+                                                        m0.triangles.astype(np.int32))
+                  mesh = mesh_cache[key]
+              except (FileNotFoundError, NotImplementedError, ValueError) as e:
+                  warnings.append(f"{n.name}: {e}")
+                  continue
+              mats = mr.get("m_Materials") or [{}]
+              material = proj.material(mats[0].get("guid")) if mats and mats[0].get("guid") else host.Material()
+              enabled = bool(mr.get("m_Enabled", 1))
+              cast = int(mr.get("m_CastShadows", 1)) == 1            # ShadowCastingMode.On
+              receive = bool(mr.get("m_ReceiveShadows", 1))
+          if mesh is None:
+              continue
+          m = n.local_to_world()
+          t = host.Transform(tuple(m[:3, 3]), tuple(n.world_rotation()), n.scale)      # position, rotation, localScale
+          t.matrix = m
+          renderers.append(host.MeshRenderer(mesh, material, t, enabled=enabled, activeInHierarchy=n.active_in_hierarchy(),
+                                             shadowCastingOn=cast, receiveShadows=receive))
+          renderers[-1].name = n.name
+      return renderers
+
+    renderers = renderers_under(mesh_parent)
+
+    # primitives under the four parents of MeshCollector (MeshCollector.cs:68-157)
+    mc_node, mc_kind = ref(rt_body, "meshCollector")
+    mc_body = mc_node.components[mc_kind] if mc_node else {}
+    collector_parents = {key: renderers_under(nodes.get((mc_body.get(key) or {}).get("fileID", 0)))
+                         for key in ("planeParent", "sphereParent", "cubeParent", "customMeshParent")}
 
     # lights under the three parents
     lis_node, lis_kind = ref(rt_body, "lightImportanceSampling")
@@ -382,7 +395,9 @@ def load_scene(scene_path: str, project_root: str, width=256, height=256, device
                       nearClipPlane=float(cam_body.get("near clip plane", 0.3)),
                       farClipPlane=float(cam_body.get("far clip plane", 1000.0)))
 
-    rt = host.RayTracing(cam, host.BVH(renderers), lis, width, height, device_id=device_id, seed_source=seed_source)
+    collector = host.MeshCollector(cam, **collector_parents)
+    rt = host.RayTracing(cam, host.BVH(renderers), lis, width, height, device_id=device_id, seed_source=seed_source,
+                         meshCollector=collector)
     names = {v: k for k, v in host.RayTracing.SamplingType.items()}
     rt.samplingType = names.get(int(rt_body.get("samplingType", 0)), "Uniform")
     rt.lightRadius = float(rt_body.get("lightRadius", 0.1))
@@ -390,7 +405,7 @@ def load_scene(scene_path: str, project_root: str, width=256, height=256, device
     rt.skyboxIntensityMulitiply = float(rt_body.get("skyboxIntensityMulitiply", 2.0))
     sc = rt_body.get("shadowColor") or {}
     rt.shadowColor = (float(sc.get("r", 0)), float(sc.get("g", 0)), float(sc.get("b", 0)))
-    rt.useBVH = bool(rt_body.get("useBVH", 1))
+    rt.useBVH = bool(rt_body.get("useBVH", 0))          # a scene saved before the field existed deserialises to false
     rt.aliasing = bool(rt_body.get("aliasing", 1))
     if (rt_body.get("matteMaskGO") or {}).get("fileID", 0):
         rt.matteMaskGO = True

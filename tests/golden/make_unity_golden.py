@@ -11,6 +11,11 @@
                                the same for Assets/Scenes/Chapter6_4.unity (20 sphere lights over five plates, MIS.png)
                                and Chapter6_2.unity (LightSampling.png)
 
+  unity_chapter3_4_primitives.npz, unity_chapter4_1_primitives.npz
+                               the buffers MeshCollector.Init would upload for two scenes that run with useBVH = false
+                               (planes / spheres / cubes; Chapter4_1 adds five custom meshes, 13444 triangles),
+                               their lights and uniforms at 320 x 200
+
 Run where the reference checkout is available:  python tests/golden/make_unity_golden.py /root/reference
 """
 import os
@@ -54,3 +59,19 @@ for name, scene in (("MIS", "Chapter6_4"), ("LightSampling", "Chapter6_2")):
     b, w, h = blocks_of(name + ".png")
     np.save(os.path.join(HERE, f"reference_{name.lower()}_blocks.npy"), b)
     export(scene + ".unity", f"unity_{scene.lower()}_scene.npz", w, h)
+
+
+def export_primitives(scene, out, w, h):
+    ls = unity.load_scene(os.path.join(root, "Assets/Scenes", scene), root, w, h)
+    rt = ls.rayTracing
+    assert not rt.useBVH
+    p = rt.meshCollector.Primitives()
+    sph, area, disc = rt.lightImportanceSampling.Lights()
+    np.savez_compressed(os.path.join(HERE, out), planes=p.planes, spheres=p.spheres, cubes=p.cubes, meshes=p.meshes, vertices=p.vertices,
+                        normals=p.normals, indices=p.indices, sphere_lights=sph, area_lights=area, disc_lights=disc,
+                        params=np.frombuffer(bytes(rt.BuildParameters()), np.uint8))
+    print(f"{scene}: {len(p.planes)} planes, {len(p.spheres)} spheres, {len(p.cubes)} cubes, {len(p.meshes)} meshes / {p.n_triangles} triangles -> {out}")
+
+
+export_primitives("Chapter3_4.unity", "unity_chapter3_4_primitives.npz", 320, 200)
+export_primitives("Chapter4_1.unity", "unity_chapter4_1_primitives.npz", 320, 200)

@@ -128,3 +128,40 @@ def test_disc_light_function_bit_exact_and_disc_lights_change_nothing(core):
         core.render_frames(seeds)
         imgs.append(core.readback(wire.IMAGE_CONVERGED))
     assert imgs[0].tobytes() == imgs[1].tobytes()
+
+
+def load_primitives_fixture(name):
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"unity_{name}_primitives.npz"))
+    prims = scenes.Primitives(z["planes"], z["spheres"], z["cubes"], z["meshes"], z["vertices"], z["normals"], z["indices"])
+    sc = scenes.Scene(name, np.zeros(0, wire.MESH_VERTEX), np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros((0, 2), np.int32),
+                      np.zeros(0, wire.MATERIAL), primitives=prims, skybox=scenes.procedural_skybox(32))
+    sc.sphere_lights, sc.area_lights, sc.disc_lights = z["sphere_lights"], z["area_lights"], z["disc_lights"]
+    sc.params = wire.RtParams.from_buffer_copy(z["params"].tobytes())
+    return sc
+
+
+@pytest.mark.parametrize("name,triangles", [("chapter3_4", 0), ("chapter4_1", 13444)])
+def test_reference_scenes_without_bvh(core, name, triangles):
+    """Assets/Scenes/Chapter3_4.unity and Chapter4_1.unity as the checkout holds them (useBVH = false; the buffers
+    MeshCollector.Init uploads were exported by tests/golden/make_unity_golden.py): first hits bit for bit, frames
+    to the radiance bound.  The reference's HDR sky is not in the checkout; a procedural one stands in."""
+    sc = load_primitives_fixture(name)
+    assert sc.primitives.n_triangles == triangles and sc.params.flags & wire.FLAG_BRUTE_FORCE
+    sc.params.width, sc.params.height = 96, 60
+    sc.params.cameraInverseProjection[:] = scenes.inverse_projection(60.0, 96 / 60).tolist()
+    core.upload(sc)
+    orc = oracle_py.Oracle(sc)
+    cam = np.array(sc.params.camera2World[12:15], np.float32)
+    rng = np.random.default_rng(2)
+    d = rng.normal(size=(50000, 3)) * (1, 0.5, 1) + (0, -0.3, 0)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    o = np.tile(cam, (len(d), 1)) + rng.normal(size=(len(d), 3)).astype(np.float32)
+    got, want = core.trace_primitives(o, d), orc.trace_primitives(o, d)
+    assert (got["primitive"] == want["primitive"]).all() and (got["primitive"] != 0xFFFFFFFF).sum() > 1000
+    H.assert_bits_equal(got["t"], want["t"], "hit.distance")
+    seeds = scenes.frame_seeds(2, seed=4)
+    core.set_params(sc.params)
+    core.set_dirty()
+    core.render_frames(seeds)
+    assert rel_l2(core.readback(wire.IMAGE_CONVERGED), oracle_py.render_frames(orc, sc.params, seeds)) <= RADIANCE_REL_L2

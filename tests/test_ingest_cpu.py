@@ -338,3 +338,22 @@ def test_reference_image_against_the_cpu_checker(oracle):
     d = np.abs(coarse(g) - coarse(want)).max(-1)
     print(f"\nchecker vs published image: median block difference {np.median(d):.1f}/255, {100 * (d <= 10).mean():.0f}% within 10")
     assert np.median(d) <= 6 and (d <= 10).mean() >= 0.8
+
+
+@needs_reference
+def test_scenes_without_bvh_load_through_the_mesh_collector():
+    """Scenes saved before `useBVH` existed deserialise it as false (RayTracing.cs:37) and take their geometry
+    from MeshCollector's four parents; the committed fixtures are exactly what the loader produces."""
+    for scene, fixture in (("Chapter3_4", "unity_chapter3_4_primitives.npz"), ("Chapter4_1", "unity_chapter4_1_primitives.npz")):
+        ls = unity.load_scene(f"{REF}/Assets/Scenes/{scene}.unity", REF, 320, 200)
+        rt = ls.rayTracing
+        assert rt.useBVH is False and rt.meshCollector is not None
+        p = rt.meshCollector.Primitives()
+        z = np.load(os.path.join(GOLDEN, fixture))
+        for key, arr in (("planes", p.planes), ("spheres", p.spheres), ("cubes", p.cubes), ("meshes", p.meshes),
+                         ("vertices", p.vertices), ("normals", p.normals), ("indices", p.indices)):
+            assert arr.tobytes() == z[key].tobytes(), (scene, key)
+        assert rt.BuildParameters().flags & wire.FLAG_BRUTE_FORCE
+    assert p.n_triangles == 13444 and len(p.meshes) == 5
+    # inactive spheres / cubes leave one zeroed element each (MeshCollector.cs:299-300)
+    assert len(p.spheres) == 1 and not p.spheres.view(np.uint8).any()
