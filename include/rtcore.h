@@ -232,6 +232,18 @@ int rt_readback_bvh(RtContext *ctx, uint32_t *morton_codes, uint32_t *sorted_tri
  * codes before DistributeMortonCode.  Either may be NULL. */
 int rt_readback_sort_stages(RtContext *ctx, uint32_t *morton_unsorted, uint32_t *morton_sorted_raw);
 
+/* The tree the rays actually walk.  No reference counterpart: the reference walks the tree
+ * above, whose Morton cells (0.24 units, fixed world box) are far coarser than the triangles
+ * of a typical scene.  The library builds a second tree over the same triangle boxes with
+ * the same steps from finer keys (include/rt_finekey.h); results are the reference's, bit
+ * for bit, because (a) which triangles a ray tests depends only on the triangles' own
+ * boxes and (b) equally distant triangles are ranked by the reference's visiting order.
+ * For checks of that build: internal nodes as 8 words each (six 16-bit grid coordinates
+ * per child box in 3 words: left box, right box, then left and right child = index, or
+ * leaf number | 0x80000000), N-1 of them; per leaf the original triangle index and its
+ * place in the reference's visiting order (N each).  Any pointer may be NULL. */
+int rt_readback_walk_tree(RtContext *ctx, uint32_t *nodes8, uint32_t *leaf_triangle, uint32_t *leaf_rank);
+
 /* ------------------------------------------------------------------ render */
 /* Every cs.Set* of RayTracing.InitShader/InitLight/InitSampling/UpdateParameters. */
 int rt_set_params(RtContext *ctx, const RtParams *params);

@@ -116,6 +116,16 @@ class Oracle:
         return dict(t=t, triangle=tri, u=u, v=v,
                     counters=dict(zip(("rays", "internalVisits", "leafVisits", "triTests", "hits"), map(int, cnt))))
 
+    def readback_walk(self):
+        """The library's traversal tree as the checker rebuilds it (same wire structs as readback_bvh) and
+        every triangle's place in the reference's visiting order."""
+        n = self.n
+        out = dict(sorted_index=np.zeros(n, np.uint32), internal=np.zeros(max(n - 1, 0), wire.INTERNAL_NODE),
+                   leaves=np.zeros(n, wire.LEAF_NODE), bvh_data=np.zeros(max(n - 1, 0), wire.AABB), visit_rank=np.zeros(n, np.uint32))
+        lib().orc_readback_walk(self.h, _p(out["sorted_index"]), _p(out["internal"]), _p(out["leaves"]), _p(out["bvh_data"]),
+                                _p(out["visit_rank"]))
+        return out
+
     def grid(self):
         """(ok, grid[6] = org xyz + step xyz, qboxes[n_internal, 6]) of the 16-bit traversal grid."""
         g = np.zeros(6, np.float32)

@@ -27,11 +27,13 @@
 #include "../include/rtcore.h"
 #include "../include/rt_math.h"
 #include "../include/rt_q16.h"
+#include "../include/rt_finekey.h"
 
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <vector>
 #ifdef _OPENMP
 #include <omp.h>
@@ -94,9 +96,15 @@ struct Scene {
     std::vector<RtAABB> bvhData;
     bool built = false;
 
-    // the library's 16-bit traversal grid (include/rt_q16.h), rebuilt here from the oracle's own tree
+    // The library's own traversal structures, rebuilt here so that its work counters can be checked:
+    // a second tree over the same triangle boxes, made by the same steps from the keys of
+    // include/rt_finekey.h (only N, triAABB and the build products of `walk` are filled), its child
+    // boxes on the 16-bit grid of include/rt_q16.h, and every triangle's place in the reference's
+    // visiting order (decides between equally distant triangles when the walk order differs).
+    std::shared_ptr<Scene> walk;
     RtQGrid grid;
-    std::vector<uint32_t> qboxes;      // 6 words per internal node: left box, right box
+    std::vector<uint32_t> qboxes;      // 6 words per internal node of `walk`: left box, right box
+    std::vector<uint32_t> visitRank;   // per original triangle
     bool gridOk = true;
 };
 
@@ -350,13 +358,57 @@ void BVHConstructor(Scene &s)
 
 // The library's traversal boxes: every child box of the tree rounded outward onto
 // the 16-bit grid of the root box (include/rt_q16.h), 3 words per box.
-void BuildGridBoxes(Scene &s)
+// The tree the library's rays walk (no reference counterpart): the reference's own steps on finer keys.
+void BuildWalkTree(Scene &s)
 {
-    s.qboxes.clear();
-    s.gridOk = true;
+    s.walk.reset();
     if (s.N < 2) return;
-    s.grid = rt_q16_grid(s.bvhData[0].min, s.bvhData[0].max);
-    s.qboxes.resize((size_t)(s.N - 1) * 6);
+    s.walk = std::make_shared<Scene>();
+    Scene &w = *s.walk;
+    w.N = s.N;
+    w.triAABB = s.triAABB;
+    const RtKeyPlan plan = rt_key_plan(s.bvhData[0].min, s.bvhData[0].max);
+    std::vector<uint32_t> keys(s.N);
+    w.sortedIdx.resize(s.N);
+    for (uint32_t i = 0; i < s.N; ++i) {
+        const RtAABB &b = s.triAABB[i];
+        keys[i] = rt_fine_key(plan, (b.min[0] + b.max[0]) * 0.5f, (b.min[1] + b.max[1]) * 0.5f, (b.min[2] + b.max[2]) * 0.5f);
+        w.sortedIdx[i] = i;
+    }
+    RadixSort(keys, w.sortedIdx);
+    DistributeMortonCode(keys, s.N);
+    w.morton = keys;
+    TreeConstructor(w);
+    BVHConstructor(w);
+}
+
+// Order in which IntersectTriangle (BVHRayTracing.cginc:78-123) meets the triangles when every box passes.
+void BuildVisitRank(Scene &s)
+{
+    s.visitRank.assign(s.N, 0);
+    if (s.N < 2) return;
+    uint32_t next = 0;
+    std::vector<uint32_t> stack;
+    stack.push_back(0);
+    while (!stack.empty()) {
+        const RtInternalNode n = s.inodes[stack.back()];
+        stack.pop_back();
+        if (n.leftNodeType == RT_INTERNAL_NODE) stack.push_back(n.leftNode);
+        else s.visitRank[s.sortedIdx[s.leaves[n.leftNode].index]] = next++;
+        if (n.rightNodeType == RT_INTERNAL_NODE) stack.push_back(n.rightNode);
+        else s.visitRank[s.sortedIdx[s.leaves[n.rightNode].index]] = next++;
+    }
+}
+
+void BuildGridBoxes(Scene &ref)
+{
+    ref.qboxes.clear();
+    ref.gridOk = true;
+    if (ref.N < 2) return;
+    ref.grid = rt_q16_grid(ref.bvhData[0].min, ref.bvhData[0].max);
+    ref.qboxes.resize((size_t)(ref.N - 1) * 6);
+    const Scene &s = *ref.walk;
+    Scene &out = ref;
     for (uint32_t i = 0; i + 1 < s.N; ++i) {
         const RtInternalNode &n = s.inodes[i];
         const uint32_t child[2] = {n.leftNode, n.rightNode}, type[2] = {n.leftNodeType, n.rightNodeType};
@@ -364,12 +416,12 @@ void BuildGridBoxes(Scene &s)
             const RtAABB &b = type[c] == RT_INTERNAL_NODE ? s.bvhData[child[c]] : s.triAABB[s.sortedIdx[s.leaves[child[c]].index]];
             uint32_t lo[3], hi[3];
             for (int a = 0; a < 3; ++a) {
-                lo[a] = rt_q16_floor(s.grid.org[a], s.grid.step[a], b.min[a]);
-                hi[a] = rt_q16_ceil(s.grid.org[a], s.grid.step[a], b.max[a]);
-                if (rt_q16_plane(s.grid.org[a], s.grid.step[a], lo[a]) > b.min[a] || hi[a] > RT_Q16_MAX) s.gridOk = false;
+                lo[a] = rt_q16_floor(out.grid.org[a], out.grid.step[a], b.min[a]);
+                hi[a] = rt_q16_ceil(out.grid.org[a], out.grid.step[a], b.max[a]);
+                if (rt_q16_plane(out.grid.org[a], out.grid.step[a], lo[a]) > b.min[a] || hi[a] > RT_Q16_MAX) out.gridOk = false;
                 if (hi[a] > RT_Q16_MAX) hi[a] = RT_Q16_MAX;
             }
-            uint32_t *w = &s.qboxes[(size_t)i * 6 + c * 3];
+            uint32_t *w = &out.qboxes[(size_t)i * 6 + c * 3];
             w[0] = lo[0] | (lo[1] << 16);
             w[1] = lo[2] | (hi[0] << 16);
             w[2] = hi[1] | (hi[2] << 16);
@@ -387,6 +439,8 @@ void Build(Scene &s)
     s.morton = keys;
     TreeConstructor(s);
     BVHConstructor(s);
+    BuildWalkTree(s);
+    BuildVisitRank(s);
     BuildGridBoxes(s);
     s.built = true;
 }
@@ -434,7 +488,10 @@ bool IntersectTriangle_MT97(const Ray &ray, f3 vert0, f3 vert1, f3 vert2, float 
 }
 
 // BVHRayTracing.cginc:41-76
-void CheckTriangle(const Scene &s, uint32_t triangleIndex, const Ray &ray, RayHit &hit, TraceCounters *cnt)
+// visitRank (library walk only, nullptr for the reference's own walk): among equally distant triangles the
+// one the reference meets first has to win, whatever order this walk meets them in.
+void CheckTriangle(const Scene &s, uint32_t triangleIndex, const Ray &ray, RayHit &hit, TraceCounters *cnt,
+                   const std::vector<uint32_t> *visitRank = nullptr)
 {
     if (cnt) cnt->leafVisits++;
     if (RayBoxIntersection(s.triAABB[triangleIndex], ray)) {
@@ -442,7 +499,10 @@ void CheckTriangle(const Scene &s, uint32_t triangleIndex, const Ray &ray, RayHi
         const RtTriangle &tri = s.tris[triangleIndex];
         float t = 0, u = 0, v = 0;
         if (IntersectTriangle_MT97(ray, ld3(tri.point0), ld3(tri.point1), ld3(tri.point2), t, u, v)) {
-            if (t > 0 && t < hit.distance) {
+            bool closer = t > 0 && t < hit.distance;
+            if (visitRank && t > 0 && t == hit.distance && hit.triangle != 0xFFFFFFFFu)
+                closer = (*visitRank)[triangleIndex] < (*visitRank)[hit.triangle];
+            if (closer) {
                 hit.distance = t;
                 hit.position = rt_add3(ray.origin, rt_scale3(ray.direction, t));
                 const f3 nsum = rt_add3(rt_add3(rt_scale3(ld3(tri.normal0), (1 - u) - v),
@@ -519,14 +579,16 @@ const RtAABB &ChildBox(const Scene &s, uint32_t node, uint32_t type)
     return type == RT_INTERNAL_NODE ? s.bvhData[node] : s.triAABB[s.sortedIdx[s.leaves[node].index]];
 }
 
-void IntersectTriangleGrid(const Scene &s, const Ray &ray, RayHit &hit, TraceCounters *cnt)
+void IntersectTriangleGrid(const Scene &ref, const Ray &ray, RayHit &hit, TraceCounters *cnt)
 {
-    if (s.N == 0) return;
+    if (ref.N == 0) return;
     if (cnt) cnt->internalVisits++;
-    if (s.N < 2 || !RayBoxIntersection(s.bvhData[0], ray)) return;
+    if (ref.N < 2 || !RayBoxIntersection(ref.bvhData[0], ray)) return;
+    // a ray with a zero / non-finite direction component walks the reference's tree with the reference's test
     const bool odd = rt_ray_needs_exact_walk(ray.origin, ray.direction);
+    const Scene &s = odd ? ref : *ref.walk;
     const f3 r = rt_mk3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
-    const RtRaySlab slab = rt_ray_slab(s.grid, ray.origin, r);
+    const RtRaySlab slab = rt_ray_slab(ref.grid, ray.origin, r);
     uint32_t stack[64];
     uint32_t sp = 0;
     stack[sp++] = 0;
@@ -540,13 +602,13 @@ void IntersectTriangleGrid(const Scene &s, const Ray &ray, RayHit &hit, TraceCou
             if (odd) {
                 pass[c] = RayBoxIntersection(ChildBox(s, child[c], type[c]), ray);
             } else {
-                const uint32_t *w = &s.qboxes[(size_t)index * 6 + c * 3];
+                const uint32_t *w = &ref.qboxes[(size_t)index * 6 + c * 3];
                 pass[c] = rt_slab_maybe(slab, w[0], w[1], w[2]);
             }
         }
         // left leaf, right leaf, then the right subtree before the left one
         for (int c = 0; c < 2; ++c)
-            if (type[c] != RT_INTERNAL_NODE && pass[c]) CheckTriangle(s, s.sortedIdx[s.leaves[child[c]].index], ray, hit, cnt);
+            if (type[c] != RT_INTERNAL_NODE && pass[c]) CheckTriangle(ref, s.sortedIdx[s.leaves[child[c]].index], ray, hit, cnt, &ref.visitRank);
         for (int c = 0; c < 2; ++c)
             if (type[c] == RT_INTERNAL_NODE && pass[c]) stack[sp++] = child[c];
         if (sp > 62) { fprintf(stderr, "oracle: traversal stack overflow\n"); abort(); }
@@ -1523,6 +1585,20 @@ void orc_trace_grid(void *h, const float *o, const float *d, uint32_t n, float *
 }
 
 // 1 when every box fitted the grid; grid6 = org[3], step[3]; qboxes = 6 words per internal node (may be NULL).
+// The library's traversal tree as rebuilt here: wire structs of the second tree (lengths as orc_readback_bvh)
+// and every triangle's place in the reference's visiting order.  Any pointer may be null.
+void orc_readback_walk(void *h, uint32_t *sortedIdx, RtInternalNode *inodes, RtLeafNode *leaves, RtAABB *bvhData, uint32_t *visitRank)
+{
+    const Scene &s = *(Scene *)h;
+    if (visitRank) memcpy(visitRank, s.visitRank.data(), s.visitRank.size() * 4);
+    if (!s.walk) return;
+    const Scene &w = *s.walk;
+    if (sortedIdx) memcpy(sortedIdx, w.sortedIdx.data(), w.sortedIdx.size() * 4);
+    if (inodes) memcpy(inodes, w.inodes.data(), w.inodes.size() * sizeof(RtInternalNode));
+    if (leaves) memcpy(leaves, w.leaves.data(), w.leaves.size() * sizeof(RtLeafNode));
+    if (bvhData) memcpy(bvhData, w.bvhData.data(), w.bvhData.size() * sizeof(RtAABB));
+}
+
 int orc_grid(void *h, float *grid6, uint32_t *qboxes)
 {
     const Scene &s = *(Scene *)h;

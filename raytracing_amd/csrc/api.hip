@@ -243,6 +243,23 @@ int rt_readback_bvh(RtContext *ctx, uint32_t *morton_codes, uint32_t *sorted_tri
                                 bvh_data);
 }
 
+int rt_readback_walk_tree(RtContext *ctx, uint32_t *nodes8, uint32_t *leaf_triangle, uint32_t *leaf_rank)
+{
+    RT_ENTER(ctx);
+    if (!ctx->built) return rt_fail(ctx, RT_E_STATE, "rt_readback_walk_tree before rt_bvh_build");
+    const uint32_t N = ctx->N;
+    if (N == 0) return RT_OK;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (nodes8 && N >= 2) RT_HIP(ctx, hipMemcpy(nodes8, ctx->dQNodes, (size_t)(N - 1) * sizeof(RtQNode), hipMemcpyDeviceToHost));
+    if (leaf_rank) RT_HIP(ctx, hipMemcpy(leaf_rank, ctx->dLeafRank, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (leaf_triangle) {
+        std::vector<RtLeafTri> rec(N);
+        RT_HIP(ctx, hipMemcpy(rec.data(), ctx->dLeafTri, (size_t)N * sizeof(RtLeafTri), hipMemcpyDeviceToHost));
+        for (uint32_t j = 0; j < N; ++j) leaf_triangle[j] = rec[j].tri;
+    }
+    return RT_OK;
+}
+
 int rt_readback_sort_stages(RtContext *ctx, uint32_t *morton_unsorted, uint32_t *morton_sorted_raw)
 {
     RT_ENTER(ctx);

@@ -10,6 +10,7 @@
 //   Assets/Shaders/BVH/BVH.compute:94-142                (k_tree)
 //   Assets/Shaders/BVH/BVH.compute:164-211               (k_fit, level-synchronous, no atomics)
 #include "rt_internal.h"
+#include "../../include/rt_finekey.h"
 
 #define WAVE 64
 #define SORT_THREADS 256
@@ -270,9 +271,10 @@ __device__ inline int delta_codes(const uint32_t *__restrict__ codes, int x, int
     return -1;
 }
 
+// rangeSize (may be null): number of leaves under each node = length of its key range
 __global__ __launch_bounds__(256) void k_tree(const uint32_t *__restrict__ codes, uint32_t N, uint32_t *__restrict__ left,
                                                uint32_t *__restrict__ right, uint32_t *__restrict__ parent,
-                                               uint32_t *__restrict__ leafParent)
+                                               uint32_t *__restrict__ leafParent, uint32_t *__restrict__ rangeSize)
 {
     const uint32_t threadId = blockIdx.x * blockDim.x + threadIdx.x;
     if (threadId >= N - 1) return;
@@ -288,6 +290,7 @@ __global__ __launch_bounds__(256) void k_tree(const uint32_t *__restrict__ codes
         if (delta_codes(codes, idx, (int)((uint32_t)idx + ((uint32_t)l + t) * (uint32_t)d), numObjects) > dmin) l += (int)t;
     const int j = idx + l * d;
     const int first = idx < j ? idx : j, last = idx < j ? j : idx;
+    if (rangeSize) rangeSize[threadId] = (uint32_t)(last - first + 1);
     // FindSplit (BVH.compute:54-92)
     int split;
     {
@@ -464,13 +467,70 @@ __global__ void k_wire_triangles(uint32_t N, const uint32_t *__restrict__ idx, c
     out[id] = t;
 }
 
+// ------------------------------------------------------------------ the traversal tree's own keys and bookkeeping
+// Sort key of the tree the rays walk (include/rt_finekey.h): the centre of the triangle's box,
+// the same (min + max) * 0.5 as k_calculate, on a 30-bit grid over the scene's own box.
+__global__ __launch_bounds__(256) void k_fine_keys(uint32_t N, const float4 *__restrict__ triAABB, RtKeyPlan plan,
+                                                    uint32_t *__restrict__ keys, uint32_t *__restrict__ triIndex)
+{
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= N) return;
+    const float4 mn = triAABB[id * 2], mx = triAABB[id * 2 + 1];
+    keys[id] = rt_fine_key(plan, (mn.x + mx.x) * 0.5f, (mn.y + mx.y) * 0.5f, (mn.z + mx.z) * 0.5f);
+    triIndex[id] = id;
+}
+
+// Position of every triangle in the reference's visiting order (BVHRayTracing.cginc:78-123: at a
+// node the left child is handled first if it is a leaf, then the right one if it is a leaf, then
+// the right subtree, then the left subtree), written at the triangle's leaf in the traversal tree.
+__global__ __launch_bounds__(256) void k_visit_rank(uint32_t N, const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
+                                                     const uint32_t *__restrict__ parent, const uint32_t *__restrict__ leafParent,
+                                                     const uint32_t *__restrict__ size, const uint32_t *__restrict__ refSortedIdx,
+                                                     const uint32_t *__restrict__ walkLeafOfTri, uint32_t *__restrict__ leafRank)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    uint32_t rank = 0, child = j | RT_LEAF_BIT, x = leafParent[j];
+    while (x != RT_INVALID) {
+        const uint32_t l = left[x], r = right[x];
+        const bool lLeaf = (l & RT_LEAF_BIT) != 0, rLeaf = (r & RT_LEAF_BIT) != 0;
+        if (l == child) rank += lLeaf ? 0u : (rLeaf ? 1u : size[r]);
+        else rank += lLeaf ? 1u : 0u;
+        child = x;
+        x = parent[x];
+    }
+    leafRank[walkLeafOfTri[refSortedIdx[j]]] = rank;
+}
+
+__global__ __launch_bounds__(256) void k_invert_leaves(uint32_t N, const uint32_t *__restrict__ walkSortedIdx, uint32_t *__restrict__ walkLeafOfTri)
+{
+    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l < N) walkLeafOfTri[walkSortedIdx[l]] = l;
+}
+
+// The exact nodes of the reference tree (walked by rays with a zero / non-finite direction component)
+// name their leaf children by the traversal tree's leaf numbers, where the triangle records live.
+__global__ __launch_bounds__(256) void k_remap_leaf_children(uint32_t NI, const uint32_t *__restrict__ refSortedIdx,
+                                                              const uint32_t *__restrict__ walkLeafOfTri, float4 *__restrict__ nodes)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NI) return;
+    float4 w = nodes[i * 4 + 3];
+    uint32_t l = __float_as_uint(w.x), r = __float_as_uint(w.y);
+    if (l & RT_LEAF_BIT) l = walkLeafOfTri[refSortedIdx[l & ~RT_LEAF_BIT]] | RT_LEAF_BIT;
+    if (r & RT_LEAF_BIT) r = walkLeafOfTri[refSortedIdx[r & ~RT_LEAF_BIT]] | RT_LEAF_BIT;
+    w.x = __uint_as_float(l);
+    w.y = __uint_as_float(r);
+    nodes[i * 4 + 3] = w;
+}
+
 // ------------------------------------------------------------------ host orchestration
 void rt_free_build(RtContext *ctx)
 {
     void **ptrs[] = {(void **)&ctx->dTriAABB, (void **)&ctx->dMortonUnsorted, (void **)&ctx->dMortonSortedRaw,
                      (void **)&ctx->dMorton, (void **)&ctx->dSortedIdx, (void **)&ctx->dLeft, (void **)&ctx->dRight,
                      (void **)&ctx->dParent, (void **)&ctx->dLeafParent, (void **)&ctx->dBvhData, (void **)&ctx->dNodes, (void **)&ctx->dQNodes,
-                     (void **)&ctx->dLeafTri, (void **)&ctx->dLeafShade};
+                     (void **)&ctx->dLeafTri, (void **)&ctx->dLeafShade, (void **)&ctx->dLeafRank};
     for (void **p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -484,6 +544,66 @@ static hipError_t dalloc(T **p, size_t count)
     return hipMalloc((void **)p, (count ? count : 1) * sizeof(T));
 }
 
+// Scratch shared by the two passes of the pipeline.
+struct BuildScratch {
+    uint32_t *keysB = nullptr, *valsB = nullptr, *blockHist = nullptr, *scanSums = nullptr, *done = nullptr;
+    uint32_t nbSort = 0, histLen = 0;
+};
+
+// sort -> duplicate-key spreading -> Karras tree -> bottom-up fit, on keys already in keysRaw / ids in sortedIdx.
+// Outputs: keysRaw (sorted), sortedIdx, codes (unique), left/right/parent/leafParent, bvhData, nodes (exact 64-byte nodes).
+static int build_tree_from_keys(RtContext *ctx, BuildScratch &sc, uint32_t N, uint32_t *keysRaw, uint32_t *sortedIdx, uint32_t *codes,
+                                uint32_t *left, uint32_t *right, uint32_t *parent, uint32_t *leafParent, uint32_t *rangeSize,
+                                RtAABB *bvhData, RtNode64 *nodes)
+{
+    hipStream_t st = ctx->stream;
+    const uint32_t NI = N - 1;
+    const dim3 blk(256), gridNI((NI + 255) / 256);
+    uint32_t *keysA = keysRaw, *valsA = sortedIdx, *keysB = sc.keysB, *valsB = sc.valsB;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = pass * 8;
+        rt_timer_begin(ctx, "k_sort_hist");
+        hipLaunchKernelGGL(k_sort_hist, dim3(sc.nbSort), dim3(SORT_THREADS), 0, st, keysA, N, shift, sc.blockHist, sc.nbSort);
+        rt_timer_end(ctx);
+        launch_scan<0>(ctx, sc.blockHist, sc.blockHist, sc.histLen, sc.scanSums);
+        rt_timer_begin(ctx, "k_sort_scatter");
+        hipLaunchKernelGGL(k_sort_scatter, dim3(sc.nbSort), dim3(SORT_THREADS), 0, st, keysA, valsA, keysB, valsB, N, shift,
+                           sc.blockHist, sc.nbSort);
+        rt_timer_end(ctx);
+        uint32_t *t = keysA; keysA = keysB; keysB = t;
+        t = valsA; valsA = valsB; valsB = t;
+    }
+    // 4 passes: the result is back in keysRaw / sortedIdx.
+    launch_scan<1>(ctx, keysRaw, codes, N, sc.scanSums);
+    if (N < 2) {
+        RT_HIP(ctx, hipMemsetAsync(leafParent, 0xFF, (size_t)N * 4, st));
+        return RT_OK;
+    }
+    RT_HIP(ctx, hipMemsetAsync(parent, 0xFF, (size_t)NI * 4, st));
+    RT_HIP(ctx, hipMemsetAsync(leafParent, 0xFF, (size_t)N * 4, st));
+    rt_timer_begin(ctx, "k_tree");
+    hipLaunchKernelGGL(k_tree, gridNI, blk, 0, st, codes, N, left, right, parent, leafParent, rangeSize);
+    rt_timer_end(ctx);
+    RT_HIP(ctx, hipMemsetAsync(sc.done, 0xFF, (size_t)NI * 4, st));
+    uint32_t rootDone = FIT_UNDONE;
+    // Tree height <= 32 (strictly growing common prefix of unique 32-bit keys).  The root is
+    // the last node to complete; look at its word every 8 levels to stop early.
+    for (uint32_t iter = 0; iter < 40 && rootDone == FIT_UNDONE; ++iter) {
+        rt_timer_begin(ctx, "k_fit");
+        hipLaunchKernelGGL(k_fit, gridNI, blk, 0, st, N, iter, left, right, sortedIdx, (const float4 *)ctx->dTriAABB, (float4 *)bvhData, sc.done,
+                           (float4 *)nodes);
+        rt_timer_end(ctx);
+        if ((iter & 7u) == 7u) {
+            RT_HIP(ctx, hipMemcpyAsync(&rootDone, sc.done, 4, hipMemcpyDeviceToHost, st));
+            RT_HIP(ctx, hipStreamSynchronize(st));
+        }
+    }
+    RT_HIP(ctx, hipMemcpyAsync(&rootDone, sc.done, 4, hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipStreamSynchronize(st));
+    if (rootDone == FIT_UNDONE) return rt_fail(ctx, RT_E_STATE, "BVH fit did not converge");
+    return RT_OK;
+}
+
 int rt_build_impl(RtContext *ctx)
 {
     const uint32_t N = ctx->N;
@@ -494,10 +614,15 @@ int rt_build_impl(RtContext *ctx)
         return RT_OK;
     }
     const uint32_t NI = N - 1;
-    uint32_t *keysB = nullptr, *valsB = nullptr, *blockHist = nullptr, *scanSums = nullptr, *done = nullptr;
-    const uint32_t nbSort = (N + SORT_TILE - 1) / SORT_TILE;
-    const uint32_t histLen = 256u * nbSort;
-    const uint32_t nbScanMax = ((histLen > N ? histLen : N) + SCAN_TILE - 1) / SCAN_TILE;
+    BuildScratch sc;
+    sc.nbSort = (N + SORT_TILE - 1) / SORT_TILE;
+    sc.histLen = 256u * sc.nbSort;
+    const uint32_t nbScanMax = ((sc.histLen > N ? sc.histLen : N) + SCAN_TILE - 1) / SCAN_TILE;
+    // the traversal tree's own build products, needed only until its nodes are quantised and its leaves packed
+    uint32_t *wKeys = nullptr, *wCodes = nullptr, *wSortedIdx = nullptr, *wLeft = nullptr, *wRight = nullptr, *wParent = nullptr,
+             *wLeafParent = nullptr, *refSize = nullptr, *walkLeafOfTri = nullptr;
+    RtAABB *wBvhData = nullptr;
+    RtNode64 *wNodes = nullptr;
 
     RT_HIP(ctx, dalloc(&ctx->dTriAABB, (size_t)N));
     RT_HIP(ctx, dalloc(&ctx->dMortonUnsorted, (size_t)N));
@@ -513,11 +638,23 @@ int rt_build_impl(RtContext *ctx)
     RT_HIP(ctx, dalloc(&ctx->dQNodes, (size_t)NI));
     RT_HIP(ctx, dalloc(&ctx->dLeafTri, (size_t)N));
     RT_HIP(ctx, dalloc(&ctx->dLeafShade, (size_t)N));
-    RT_HIP(ctx, dalloc(&keysB, (size_t)N));
-    RT_HIP(ctx, dalloc(&valsB, (size_t)N));
-    RT_HIP(ctx, dalloc(&blockHist, (size_t)histLen));
-    RT_HIP(ctx, dalloc(&scanSums, (size_t)nbScanMax + 1));
-    RT_HIP(ctx, dalloc(&done, (size_t)NI));
+    RT_HIP(ctx, dalloc(&ctx->dLeafRank, (size_t)N));
+    RT_HIP(ctx, dalloc(&sc.keysB, (size_t)N));
+    RT_HIP(ctx, dalloc(&sc.valsB, (size_t)N));
+    RT_HIP(ctx, dalloc(&sc.blockHist, (size_t)sc.histLen));
+    RT_HIP(ctx, dalloc(&sc.scanSums, (size_t)nbScanMax + 1));
+    RT_HIP(ctx, dalloc(&sc.done, (size_t)NI));
+    RT_HIP(ctx, dalloc(&wKeys, (size_t)N));
+    RT_HIP(ctx, dalloc(&wCodes, (size_t)N));
+    RT_HIP(ctx, dalloc(&wSortedIdx, (size_t)N));
+    RT_HIP(ctx, dalloc(&wLeft, (size_t)NI));
+    RT_HIP(ctx, dalloc(&wRight, (size_t)NI));
+    RT_HIP(ctx, dalloc(&wParent, (size_t)NI));
+    RT_HIP(ctx, dalloc(&wLeafParent, (size_t)N));
+    RT_HIP(ctx, dalloc(&refSize, (size_t)NI));
+    RT_HIP(ctx, dalloc(&walkLeafOfTri, (size_t)N));
+    RT_HIP(ctx, dalloc(&wBvhData, (size_t)NI));
+    RT_HIP(ctx, dalloc(&wNodes, (size_t)NI));
 
     hipStream_t st = ctx->stream;
     hipEvent_t e0, e1;
@@ -527,69 +664,53 @@ int rt_build_impl(RtContext *ctx)
 
     const dim3 blk(256);
     const dim3 gridN((N + 255) / 256), gridNI((NI + 255) / 256);
-    uint32_t *keysA = ctx->dMortonSortedRaw, *valsA = ctx->dSortedIdx;
+    int rc;
 
+    // ---- the reference's tree (what rt_readback_bvh returns; walked only by rays with a zero or
+    //      non-finite direction component, and the source of every triangle's visiting rank)
     rt_timer_begin(ctx, "k_calculate");
     hipLaunchKernelGGL(k_calculate, gridN, blk, 0, st, ctx->dIdx, (const float *)ctx->dVerts, N, (float4 *)ctx->dTriAABB,
-                       ctx->dMortonUnsorted, valsA);
+                       ctx->dMortonUnsorted, ctx->dSortedIdx);
     rt_timer_end(ctx);
-    RT_HIP(ctx, hipMemcpyAsync(keysA, ctx->dMortonUnsorted, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
-
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = pass * 8;
-        rt_timer_begin(ctx, "k_sort_hist");
-        hipLaunchKernelGGL(k_sort_hist, dim3(nbSort), dim3(SORT_THREADS), 0, st, keysA, N, shift, blockHist, nbSort);
-        rt_timer_end(ctx);
-        launch_scan<0>(ctx, blockHist, blockHist, histLen, scanSums);
-        rt_timer_begin(ctx, "k_sort_scatter");
-        hipLaunchKernelGGL(k_sort_scatter, dim3(nbSort), dim3(SORT_THREADS), 0, st, keysA, valsA, keysB, valsB, N, shift,
-                           blockHist, nbSort);
-        rt_timer_end(ctx);
-        uint32_t *t = keysA; keysA = keysB; keysB = t;
-        t = valsA; valsA = valsB; valsB = t;
-    }
-    // 4 passes: the result is back in dMortonSortedRaw / dSortedIdx.
-
-    launch_scan<1>(ctx, ctx->dMortonSortedRaw, ctx->dMorton, N, scanSums);
+    RT_HIP(ctx, hipMemcpyAsync(ctx->dMortonSortedRaw, ctx->dMortonUnsorted, (size_t)N * 4, hipMemcpyDeviceToDevice, st));
+    if ((rc = build_tree_from_keys(ctx, sc, N, ctx->dMortonSortedRaw, ctx->dSortedIdx, ctx->dMorton, ctx->dLeft, ctx->dRight, ctx->dParent,
+                                   ctx->dLeafParent, refSize, ctx->dBvhData, ctx->dNodes)))
+        return rc;
 
     if (N >= 2) {
-        RT_HIP(ctx, hipMemsetAsync(ctx->dParent, 0xFF, (size_t)NI * 4, st));
-        RT_HIP(ctx, hipMemsetAsync(ctx->dLeafParent, 0xFF, (size_t)N * 4, st));
-        rt_timer_begin(ctx, "k_tree");
-        hipLaunchKernelGGL(k_tree, gridNI, blk, 0, st, ctx->dMorton, N, ctx->dLeft, ctx->dRight, ctx->dParent,
-                           ctx->dLeafParent);
-        rt_timer_end(ctx);
-        RT_HIP(ctx, hipMemsetAsync(done, 0xFF, (size_t)NI * 4, st));
-        uint32_t rootDone = FIT_UNDONE;
-        // Tree height <= 32 (strictly growing common prefix of unique 32-bit keys).  The root is
-        // the last node to complete; look at its word every 8 levels to stop early.
-        for (uint32_t iter = 0; iter < 40 && rootDone == FIT_UNDONE; ++iter) {
-            rt_timer_begin(ctx, "k_fit");
-            hipLaunchKernelGGL(k_fit, gridNI, blk, 0, st, N, iter, ctx->dLeft, ctx->dRight, ctx->dSortedIdx,
-                               (const float4 *)ctx->dTriAABB, (float4 *)ctx->dBvhData, done, (float4 *)ctx->dNodes);
-            rt_timer_end(ctx);
-            if ((iter & 7u) == 7u) {
-                RT_HIP(ctx, hipMemcpyAsync(&rootDone, done, 4, hipMemcpyDeviceToHost, st));
-                RT_HIP(ctx, hipStreamSynchronize(st));
-            }
-        }
-        RT_HIP(ctx, hipMemcpyAsync(&rootDone, done, 4, hipMemcpyDeviceToHost, st));
-        RT_HIP(ctx, hipStreamSynchronize(st));
-        if (rootDone == FIT_UNDONE) return rt_fail(ctx, RT_E_STATE, "BVH fit did not converge");
         RT_HIP(ctx, hipMemcpyAsync(&ctx->rootBox, ctx->dBvhData, sizeof(RtAABB), hipMemcpyDeviceToHost, st));
         RT_HIP(ctx, hipStreamSynchronize(st));
         ctx->grid = rt_q16_grid(ctx->rootBox.min, ctx->rootBox.max);
+
+        // ---- the tree the rays walk: same pipeline, keys on a fine grid over the scene's own box
+        const RtKeyPlan plan = rt_key_plan(ctx->rootBox.min, ctx->rootBox.max);
+        rt_timer_begin(ctx, "k_fine_keys");
+        hipLaunchKernelGGL(k_fine_keys, gridN, blk, 0, st, N, (const float4 *)ctx->dTriAABB, plan, wKeys, wSortedIdx);
+        rt_timer_end(ctx);
+        if ((rc = build_tree_from_keys(ctx, sc, N, wKeys, wSortedIdx, wCodes, wLeft, wRight, wParent, wLeafParent, nullptr, wBvhData, wNodes)))
+            return rc;
         rt_timer_begin(ctx, "k_quantise");
-        hipLaunchKernelGGL(k_quantise, gridNI, blk, 0, st, NI, ctx->grid, ctx->dNodes, (uint4 *)ctx->dQNodes, ctx->dErrorFlag);
+        hipLaunchKernelGGL(k_quantise, gridNI, blk, 0, st, NI, ctx->grid, wNodes, (uint4 *)ctx->dQNodes, ctx->dErrorFlag);
+        rt_timer_end(ctx);
+        rt_timer_begin(ctx, "k_pack_leaves");
+        hipLaunchKernelGGL(k_pack_leaves, gridN, blk, 0, st, N, wSortedIdx, ctx->dIdx, (const float *)ctx->dVerts, ctx->dMatIdx, ctx->dShadow,
+                           (const float4 *)ctx->dTriAABB, (float4 *)ctx->dLeafTri, (float4 *)ctx->dLeafShade);
+        rt_timer_end(ctx);
+        // ---- tie the two together: visiting rank per leaf, leaf numbers in the reference tree's exact nodes
+        rt_timer_begin(ctx, "k_visit_rank");
+        hipLaunchKernelGGL(k_invert_leaves, gridN, blk, 0, st, N, wSortedIdx, walkLeafOfTri);
+        hipLaunchKernelGGL(k_visit_rank, gridN, blk, 0, st, N, ctx->dLeft, ctx->dRight, ctx->dParent, ctx->dLeafParent, refSize, ctx->dSortedIdx,
+                           walkLeafOfTri, ctx->dLeafRank);
+        hipLaunchKernelGGL(k_remap_leaf_children, gridNI, blk, 0, st, NI, ctx->dSortedIdx, walkLeafOfTri, (float4 *)ctx->dNodes);
         rt_timer_end(ctx);
     } else {
-        RT_HIP(ctx, hipMemsetAsync(ctx->dLeafParent, 0xFF, (size_t)N * 4, st));
+        // a single triangle: no internal node, nothing can be hit (bvhData[0] is the zero box); records in input order
+        rt_timer_begin(ctx, "k_pack_leaves");
+        hipLaunchKernelGGL(k_pack_leaves, gridN, blk, 0, st, N, ctx->dSortedIdx, ctx->dIdx, (const float *)ctx->dVerts, ctx->dMatIdx, ctx->dShadow,
+                           (const float4 *)ctx->dTriAABB, (float4 *)ctx->dLeafTri, (float4 *)ctx->dLeafShade);
+        rt_timer_end(ctx);
+        RT_HIP(ctx, hipMemsetAsync(ctx->dLeafRank, 0, (size_t)N * 4, st));
     }
-    rt_timer_begin(ctx, "k_pack_leaves");
-    hipLaunchKernelGGL(k_pack_leaves, gridN, blk, 0, st, N, ctx->dSortedIdx, ctx->dIdx, (const float *)ctx->dVerts,
-                       ctx->dMatIdx, ctx->dShadow, (const float4 *)ctx->dTriAABB, (float4 *)ctx->dLeafTri,
-                       (float4 *)ctx->dLeafShade);
-    rt_timer_end(ctx);
 
     RT_HIP(ctx, hipEventRecord(e1, st));
     RT_HIP(ctx, hipStreamSynchronize(st));
@@ -599,11 +720,9 @@ int rt_build_impl(RtContext *ctx)
     ctx->buildMs = ms;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    (void)hipFree(keysB);
-    (void)hipFree(valsB);
-    (void)hipFree(blockHist);
-    (void)hipFree(scanSums);
-    (void)hipFree(done);
+    void *scratch[] = {sc.keysB, sc.valsB, sc.blockHist, sc.scanSums, sc.done, wKeys, wCodes, wSortedIdx, wLeft, wRight, wParent,
+                       wLeafParent, refSize, walkLeafOfTri, wBvhData, wNodes};
+    for (void *q : scratch) (void)hipFree(q);
     ctx->built = true;
     return RT_OK;
 }

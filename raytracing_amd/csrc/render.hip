@@ -555,6 +555,7 @@ RtSceneView rt_scene_view(RtContext *ctx)
     sv.grid = ctx->grid;
     sv.leafTri = ctx->dLeafTri;
     sv.leafShade = ctx->dLeafShade;
+    sv.leafRank = ctx->dLeafRank;
     sv.materials = ctx->dMats;
     sv.nMaterials = ctx->nMats;
     sv.nTriangles = ctx->N;

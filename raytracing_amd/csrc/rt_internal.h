@@ -70,6 +70,7 @@ struct RtSceneView {
     RtQGrid grid;
     const RtLeafTri *leafTri;
     const RtLeafShade *leafShade;
+    const uint32_t *leafRank;  // reference visiting order of each leaf's triangle (decides between equal distances)
     const RtMaterialData *materials;
     uint32_t nMaterials;
     uint32_t nTriangles;
@@ -179,6 +180,7 @@ struct RtContext {
     RtQGrid grid;
     RtLeafTri *dLeafTri = nullptr;
     RtLeafShade *dLeafShade = nullptr;
+    uint32_t *dLeafRank = nullptr;        // per traversal-tree leaf: position of its triangle in the reference's visiting order
     RtAABB rootBox;
     bool built = false;
 

@@ -95,8 +95,12 @@ __device__ __forceinline__ bool box_hit(float bminx, float bminy, float bminz, f
 
 // IntersectTriangle_MT97 + the acceptance test of CheckTriangle.
 // (returns whether h was replaced)
+// The reference keeps the FIRST triangle it meets among equally distant ones (strict '<' in its
+// own visiting order).  A walker that meets triangles in another order passes `leafRank`, the
+// position of every leaf's triangle in that order, and lets the earlier one win a tie; a walker
+// that follows the reference's order passes nullptr.
 __device__ __forceinline__ bool tri_test_values(const rt_f3 v0, const rt_f3 e1, const rt_f3 e2, uint32_t leaf, const rt_f3 o,
-                                                const rt_f3 d, RtHitRec &h)
+                                                const rt_f3 d, RtHitRec &h, const uint32_t *__restrict__ leafRank = nullptr)
 {
     const rt_f3 pvec = rt_cross3(d, e2);
     const float det = rt_dot3(e1, pvec);
@@ -109,7 +113,9 @@ __device__ __forceinline__ bool tri_test_values(const rt_f3 v0, const rt_f3 e1, 
     const float v = rt_dot3(d, qvec) * inv_det;
     if (v < 0.0f || u + v > 1.0f) return false;
     const float t = rt_dot3(e2, qvec) * inv_det;
-    if (t > 0.0f && t < h.t) {
+    bool closer = t > 0.0f && t < h.t;
+    if (leafRank && t > 0.0f && t == h.t && h.leaf != RT_INVALID) closer = leafRank[leaf] < leafRank[h.leaf];
+    if (closer) {
         h.t = t;
         h.u = u;
         h.v = v;
@@ -136,11 +142,11 @@ __device__ __forceinline__ bool tri_test(const RtSceneView &sv, uint32_t leaf, c
     if (COUNT) {
         const float4 e = p[3];
         if (!box_hit(c.z, c.w, e.x, e.y, e.z, e.w, o, d, r)) return false;
-        tri_test_values(v0, e1, e2, leaf, o, d, h);
+        tri_test_values(v0, e1, e2, leaf, o, d, h, sv.leafRank);
         return true;
     }
     RtHitRec cand = h;
-    if (tri_test_values(v0, e1, e2, leaf, o, d, cand)) {              // Moller-Trumbore would accept it
+    if (tri_test_values(v0, e1, e2, leaf, o, d, cand, sv.leafRank)) {              // Moller-Trumbore would accept it
         const float4 e = p[3];
         if (box_hit(c.z, c.w, e.x, e.y, e.z, e.w, o, d, r)) h = cand;
     }

@@ -24,6 +24,7 @@ EXPORTS = [
     "rt_kernel_time", "rt_synchronize", "rt_version", "rt_debug_eval", "rt_set_option",
     "rt_image_upload", "rt_image_size", "rt_post_blit", "rt_post_color_correction", "rt_post_lut_upload",
     "rt_post_color_grading", "rt_post_bloom", "rt_save_rgb24", "rt_primitives_upload", "rt_trace_primitives",
+    "rt_readback_walk_tree",
 ]
 
 _lib = None
@@ -164,6 +165,13 @@ class RtCore:
         self._check(self.lib.rt_readback_sort_stages(self.ctx, _p(un), _p(raw)))
         out["morton_unsorted"], out["morton_sorted_raw"] = un, raw
         return out
+
+    def readback_walk_tree(self):
+        """The tree the rays walk: nodes u32[N-1, 8], per leaf the triangle and its reference visiting rank."""
+        n = self.n_triangles
+        nodes, tri, rank = np.zeros((max(n - 1, 0), 8), np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        self._check(self.lib.rt_readback_walk_tree(self.ctx, _p(nodes), _p(tri), _p(rank)))
+        return dict(nodes=nodes, leaf_triangle=tri, leaf_rank=rank)
 
     # ---- render
     def set_params(self, params):

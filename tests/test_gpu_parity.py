@@ -328,3 +328,59 @@ def test_error_codes(core):
         core.set_params(sc.params)
         core.dispatch()                       # scene uploaded but not built
     assert e.value.code == -4
+
+
+@pytest.mark.parametrize("name", ["cornell", "soup20k", "dups", "tiny2", "tiny3", "tiny4097"])
+def test_walk_tree_bit_exact(core, oracle, name):
+    """The tree the rays walk (same build steps, finer keys) and every triangle's place in the reference's visiting
+    order: device build against the checker's, word for word."""
+    sc = _scene(name)
+    orc = oracle.Oracle(sc).build()
+    core.upload(sc)
+    core.bvh_build()
+    got, want = core.readback_walk_tree(), orc.readback_walk()
+    n = sc.n_triangles
+    assert (got["leaf_triangle"] == want["sorted_index"]).all()
+    assert (got["leaf_rank"] == want["visit_rank"][want["sorted_index"]]).all()
+    assert sorted(got["leaf_rank"].tolist()) == list(range(n))
+    ok, _, qboxes = orc.grid()
+    assert ok
+    nodes = want["internal"]
+    child = lambda side: nodes[side + "Node"] | np.where(nodes[side + "NodeType"] != 0, np.uint32(0x80000000), np.uint32(0))
+    H.assert_bits_equal(got["nodes"][:, :6], qboxes, "grid boxes of the traversal tree")
+    assert (got["nodes"][:, 6] == child("left")).all() and (got["nodes"][:, 7] == child("right")).all()
+
+
+def test_equal_distances_go_to_the_reference_first_visited(core, oracle):
+    """Coincident triangles give exactly equal distances; the reference keeps the one its own loop meets first.
+    The library meets them in another order (another tree) and must still report that one."""
+    rs = np.random.Generator(np.random.PCG64(5))
+    base = scenes.triangle_soup(400, seed=3, extent=2.0, edge=0.8)
+    reps = 6
+    v = np.tile(base.vertices, reps)
+    idx = np.concatenate([base.indices + k * len(base.vertices) for k in range(reps)])
+    order = rs.permutation(400 * reps)                              # shuffle so that copies are far apart in the input
+    sc = scenes.Scene("coincident", v, idx.reshape(-1, 3)[order].reshape(-1), np.tile(base.material_index, reps)[order],
+                      np.tile(base.shadow_index, (reps, 1))[order], base.materials, params=base.params)
+    orc = oracle.Oracle(sc).build()
+    core.upload(sc)
+    core.bvh_build()
+    o, d = H.random_rays(50000, 17, -2, 2)
+    got, want = core.trace_rays(o, d), orc.trace(o, d)
+    hit = want["triangle"] != 0xFFFFFFFF
+    assert hit.sum() > 5000
+    assert (got["triangle"] == want["triangle"]).all()
+    H.assert_bits_equal(got["t"], want["t"], "hit distance")
+    # the tie-break really decided: in the library's own order another copy would have come first for many rays
+    walk = orc.readback_walk()
+    leaf_of = np.empty(len(order), np.int64)
+    leaf_of[walk["sorted_index"]] = np.arange(len(order))
+    groups = {}                                                    # input triangle i is a copy of base triangle order[i] % 400
+    for i, t in enumerate(order):
+        groups.setdefault(int(t) % 400, []).append(i)
+    decided = 0
+    for t in np.unique(want["triangle"][hit])[:200]:
+        g = groups[int(order[t]) % 400]
+        if min(g, key=lambda i: leaf_of[i]) != min(g, key=lambda i: walk["visit_rank"][i]):
+            decided += 1
+    assert decided > 20

@@ -233,7 +233,8 @@ def test_grid_boxes_contain_the_exact_boxes(oracle):
     orc = oracle.Oracle(sc).build()
     ok, g, q = orc.grid()
     assert ok
-    bvh = orc.readback_bvh()
+    bvh = orc.readback_walk()                        # the grid boxes belong to the tree the library walks
+    bvh["tri_aabb"] = orc.readback_bvh()["tri_aabb"]
     org, step = g[:3], g[3:]
     nodes, leaves = bvh["internal"], bvh["leaves"]
     for side, off in (("left", 0), ("right", 3)):
@@ -417,3 +418,60 @@ def test_matte_mask_and_shadowmap_alpha(oracle):
     assert set(np.unique(sm[..., 3])) <= {0.0, 1.0}
     assert (sm[..., 3] == 1).any() and (sm[..., 3] == 0).any()       # car pixels 1, ground (type 4) and sky 0
     assert sm[..., :3].min() >= 1 - sc.params.shadowParameter[3] - 1e-6
+
+
+def test_walk_tree_and_visit_rank(oracle):
+    """The second tree is a complete binary tree over the same triangles, sorted by the finer keys, and the visiting
+    rank is the order in which the reference's loop (left leaf, right leaf, right subtree, left subtree) meets them."""
+    sc = scenes.car_standin(32, 32, detail=0.03)
+    orc = oracle.Oracle(sc).build()
+    ref, walk = orc.readback_bvh(), orc.readback_walk()
+    n = sc.n_triangles
+    assert sorted(walk["sorted_index"].tolist()) == list(range(n))
+    # every leaf and every internal node but the root has exactly one parent
+    kids = np.concatenate([walk["internal"]["leftNode"] + n * (walk["internal"]["leftNodeType"] != 0),
+                           walk["internal"]["rightNode"] + n * (walk["internal"]["rightNodeType"] != 0)])
+    assert sorted(kids.tolist()) == list(range(1, n - 1)) + list(range(n, 2 * n))
+    # boxes of the second tree enclose their triangles: the root boxes of both trees are the same union
+    assert walk["bvh_data"][0].tobytes() == ref["bvh_data"][0].tobytes()
+    # rank: recursive statement of the visiting order
+    import sys
+    sys.setrecursionlimit(10000)
+    order = []
+
+    def visit(i):
+        nd = ref["internal"][i]
+        if nd["leftNodeType"] != 0:
+            order.append(int(ref["sorted_index"][nd["leftNode"]]))
+        if nd["rightNodeType"] != 0:
+            order.append(int(ref["sorted_index"][nd["rightNode"]]))
+        if nd["rightNodeType"] == 0:
+            visit(int(nd["rightNode"]))
+        if nd["leftNodeType"] == 0:
+            visit(int(nd["leftNode"]))
+
+    visit(0)
+    assert len(order) == n
+    assert (walk["visit_rank"][np.array(order)] == np.arange(n)).all()
+    # the finer keys pay off: fewer box tests for the same rays, same hits
+    o, d = H.random_rays(3000, 21, -2, 2)
+    a, b = orc.trace(o, d), orc.trace(o, d, grid=True)
+    assert a["t"].tobytes() == b["t"].tobytes() and (a["triangle"] == b["triangle"]).all()
+    assert b["counters"]["internalVisits"] < a["counters"]["internalVisits"]
+
+
+def test_grid_walk_keeps_the_reference_winner_among_coincident_triangles(oracle):
+    rs = np.random.Generator(np.random.PCG64(5))
+    base = scenes.triangle_soup(300, seed=3, extent=2.0, edge=0.8)
+    reps = 5
+    v = np.tile(base.vertices, reps)
+    idx = np.concatenate([base.indices + k * len(base.vertices) for k in range(reps)])
+    order = rs.permutation(300 * reps)
+    sc = scenes.Scene("coincident", v, idx.reshape(-1, 3)[order].reshape(-1), np.tile(base.material_index, reps)[order],
+                      np.tile(base.shadow_index, (reps, 1))[order], base.materials, params=base.params)
+    orc = oracle.Oracle(sc).build()
+    o, d = H.random_rays(20000, 17, -2, 2)
+    a, b = orc.trace(o, d), orc.trace(o, d, grid=True)
+    assert (a["triangle"] != 0xFFFFFFFF).sum() > 2000
+    assert (a["triangle"] == b["triangle"]).all() and a["t"].tobytes() == b["t"].tobytes()
+    assert a["u"].tobytes() == b["u"].tobytes() and a["v"].tobytes() == b["v"].tobytes()
