@@ -372,7 +372,7 @@ void BuildWalkTree(Scene &s)
     w.sortedIdx.resize(s.N);
     for (uint32_t i = 0; i < s.N; ++i) {
         const RtAABB &b = s.triAABB[i];
-        keys[i] = rt_fine_key(plan, (b.min[0] + b.max[0]) * 0.5f, (b.min[1] + b.max[1]) * 0.5f, (b.min[2] + b.max[2]) * 0.5f);
+        keys[i] = rt_fine_key(plan, b.min, b.max);
         w.sortedIdx[i] = i;
     }
     RadixSort(keys, w.sortedIdx);

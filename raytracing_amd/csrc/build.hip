@@ -469,14 +469,15 @@ __global__ void k_wire_triangles(uint32_t N, const uint32_t *__restrict__ idx, c
 
 // ------------------------------------------------------------------ the traversal tree's own keys and bookkeeping
 // Sort key of the tree the rays walk (include/rt_finekey.h): the centre of the triangle's box,
-// the same (min + max) * 0.5 as k_calculate, on a 30-bit grid over the scene's own box.
+// the same (min + max) * 0.5 as k_calculate, on a 29-bit grid over the scene's own box, under 2 bits for the size of the box.
 __global__ __launch_bounds__(256) void k_fine_keys(uint32_t N, const float4 *__restrict__ triAABB, RtKeyPlan plan,
                                                     uint32_t *__restrict__ keys, uint32_t *__restrict__ triIndex)
 {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= N) return;
     const float4 mn = triAABB[id * 2], mx = triAABB[id * 2 + 1];
-    keys[id] = rt_fine_key(plan, (mn.x + mx.x) * 0.5f, (mn.y + mx.y) * 0.5f, (mn.z + mx.z) * 0.5f);
+    const float lo[3] = {mn.x, mn.y, mn.z}, hi[3] = {mx.x, mx.y, mx.z};
+    keys[id] = rt_fine_key(plan, lo, hi);
     triIndex[id] = id;
 }
 

@@ -399,15 +399,45 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
 
         TRV_PHASE(1)
         // ---- triangle phase: every lane tests its queued triangles in the order it met them
-        for (uint32_t k = 0; __ballot(k < npend) != 0ull; ++k)
+        if (COUNT) {
+            for (uint32_t k = 0; __ballot(k < npend) != 0ull; ++k)
+                if (k < npend) {
+                    const bool boxed = tri_test<COUNT>(sv, pend[k * TRV_THREADS], o, d, r, h);
+                    cnt[1]++;
+                    cnt[2] += boxed ? 1u : 0u;
+                }
+        } else {
+            // Two triangles per trip: both records are requested before either is looked at, so a lane with
+            // several queued triangles pays the memory round trip once per pair (the tests themselves are
+            // short; the trip time is the latency of the 48-byte fetch).  Lanes with nothing queued fetch
+            // record 0 (one cache line for the whole wave) and skip the test.
+            for (uint32_t k = 0; __ballot(k < npend) != 0ull; k += 2u) {
 #ifdef TRV_PROFILE
-            if (pN[3]++, pN[4] += (unsigned long long)__popcll(__ballot(k < npend)), k < npend) {
-#else
-            if (k < npend) {
+                pN[3]++;
+                pN[4] += (unsigned long long)__popcll(__ballot(k < npend));
 #endif
-                const bool boxed = tri_test<COUNT>(sv, pend[k * TRV_THREADS], o, d, r, h);
-                if (COUNT) { cnt[1]++; cnt[2] += boxed ? 1u : 0u; }
+                const bool t0 = k < npend, t1 = k + 1u < npend;
+                const uint32_t leaf0 = t0 ? pend[k * TRV_THREADS] : 0u;
+                const uint32_t leaf1 = t1 ? pend[(k + 1u) * TRV_THREADS] : 0u;
+                const float4 *p0 = (const float4 *)(sv.leafTri + leaf0), *p1 = (const float4 *)(sv.leafTri + leaf1);
+                const float4 a0 = p0[0], b0 = p0[1], c0 = p0[2];
+                const float4 a1 = p1[0], b1 = p1[1], c1 = p1[2];
+                if (t0) {
+                    RtHitRec cand = h;
+                    if (tri_test_values(rt_mk3(a0.x, a0.y, a0.z), rt_mk3(a0.w, b0.x, b0.y), rt_mk3(b0.z, b0.w, c0.x), leaf0, o, d, cand, sv.leafRank)) {
+                        const float4 e = p0[3];
+                        if (box_hit(c0.z, c0.w, e.x, e.y, e.z, e.w, o, d, r)) h = cand;
+                    }
+                }
+                if (t1) {
+                    RtHitRec cand = h;
+                    if (tri_test_values(rt_mk3(a1.x, a1.y, a1.z), rt_mk3(a1.w, b1.x, b1.y), rt_mk3(b1.z, b1.w, c1.x), leaf1, o, d, cand, sv.leafRank)) {
+                        const float4 e = p1[3];
+                        if (box_hit(c1.z, c1.w, e.x, e.y, e.z, e.w, o, d, r)) h = cand;
+                    }
+                }
             }
+        }
         npend = 0;
         TRV_PHASE(2)
 
