@@ -75,6 +75,7 @@ public static class RtCoreNative
     [DllImport(Lib)] public static extern int rt_bvh_build(IntPtr ctx);
     [DllImport(Lib)] public static extern int rt_readback_bvh(IntPtr ctx, uint[] morton, uint[] sortedIndex, AABB[] triangleAabb, Triangle[] triangles,
                                                                InternalNode[] internalNodes, LeafNode[] leafNodes, AABB[] bvhData);
+    [DllImport(Lib)] public static extern int rt_readback_walk_tree(IntPtr ctx, uint[] nodes8, uint[] leafTriangle, uint[] leafRank);
     [DllImport(Lib)] public static extern int rt_set_params(IntPtr ctx, ref RtParams p);
     [DllImport(Lib)] public static extern int rt_dispatch(IntPtr ctx);
     [DllImport(Lib)] public static extern int rt_dispatch_shadowmap(IntPtr ctx);

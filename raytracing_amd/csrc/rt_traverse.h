@@ -13,14 +13,18 @@
 //     components IEEE subtraction and division are monotone, so a ray that passes
 //     a triangle's own box passes every box that contains it: the set of triangles
 //     the reference ends up testing is exactly "own box passes", and the order it
-//     meets them in is fixed by the tree.  Any walk of the same tree, in the same
-//     child order, that never skips a subtree holding such a triangle returns the
-//     same hit, bit for bit.  The one-ray-per-lane walker therefore reads 32-byte
-//     nodes whose child boxes are rounded OUTWARD onto a 16-bit grid (rt_q16.h)
-//     and tests them with a cheap test that may say "maybe" but never a wrong
-//     "no"; the triangle's own box is exact and gets the reference's test.
-//     Rays outside the monotone case (a zero / infinite / NaN component) walk the
-//     exact 64-byte nodes with the reference's test at every node instead.
+//     meets them in is a fixed permutation of the triangles (its loop's order does
+//     not depend on which boxes pass).  Any walk of ANY tree over the same triangle
+//     boxes that never skips a subtree holding such a triangle, and that lets the
+//     triangle the reference meets first win among exactly equal distances
+//     (leafRank), returns the same hit, bit for bit.  The one-ray-per-lane walker
+//     therefore walks a second tree, built from finer keys than the reference's
+//     (include/rt_finekey.h), through 32-byte nodes whose child boxes are rounded
+//     OUTWARD onto a 16-bit grid (rt_q16.h), with a cheap test that may say "maybe"
+//     but never a wrong "no"; the triangle's own box is exact and gets the
+//     reference's test.  Rays outside the monotone case (a zero / infinite / NaN
+//     component) walk the reference's own tree, exact 64-byte nodes with the
+//     reference's test at every node, and so does the packet walker.
 //   * the reference's slab test is first evaluated with per-ray reciprocals and an
 //     error margin; only when the margin cannot decide (a graze within a few ulp,
 //     an infinity, a NaN) are the six true divisions evaluated, so the boolean is
