@@ -375,7 +375,8 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *   RT_OPT_TWO_STREAMS     0 (default): 1 = the frames in flight go down two HIP streams, half each
  *                          (measured 3 % slower: the walkers already fill the chip)
  *   RT_OPT_BATCH_FRAMES    1..64 frames rt_render_frames keeps in flight; 0 (default): as many as give
- *                          about 16 M paths per launch (8 for a whole 1080p frame, 64 for an eighth of it) */
+ *                          up to 128 M paths per launch (64 for a whole 1080p frame, 16 for a 4K frame; 164 bytes of
+ *                          device memory per path, halved until it fits) */
 #define RT_OPT_PACKET_SHADOW 0
 #define RT_OPT_PACKET_PRIMARY 1
 #define RT_OPT_PACKET_TRACE 2
