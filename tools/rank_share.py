@@ -16,6 +16,8 @@ core.upload(sc); core.bvh_build()
 p = sc.params.copy()
 p.tileRank, p.tileCount, p.tileSize = 0, world, 64
 core.set_params(p)
+for kv in filter(None, os.environ.get("RT_OPTS", "").split(",")):     # rt_set_option pairs, e.g. RT_OPTS=5=1
+    k, v = kv.split("="); core.set_option(int(k), int(v))
 seeds = scenes.frame_seeds(spp, 1)
 core.render_frames(seeds)
 out = []
