@@ -194,7 +194,7 @@ class LoadedScene:
 
 
 def unity_builtin_mesh(name):
-    """Unity's built-in primitives (Quad, Cube, Plane exact by construction; Sphere approximated)."""
+    """Unity's built-in primitives (Quad, Cube, Plane exact by construction; Sphere and Cylinder approximated)."""
     if name == "Quad":
         return scenes.quad_mesh()
     if name == "Cube":
@@ -207,6 +207,8 @@ def unity_builtin_mesh(name):
                            q.tangents, q.uvs, q.triangles)
     if name == "Sphere":
         return scenes.uv_sphere_mesh(24, 16, radius=0.5)
+    if name == "Cylinder":
+        return scenes.cylinder_mesh(20)
     raise NotImplementedError(f"built-in mesh {name}")
 
 
@@ -415,6 +417,38 @@ def load_scene(scene_path: str, project_root: str, width=256, height=256, device
         c = lb.get("m_Color") or {}
         rt.mainLightColor = (float(c.get("r", 1)), float(c.get("g", 1)), float(c.get("b", 1)))
         rt.mainLightForward = tuple(scenes.quat_rotate(light_node.world_rotation(), np.array([0.0, 0.0, 1.0])))
+    # PostProcessStack and its stages (PostProcessStack.cs:7-10); a stage's `enabled` is its m_Enabled
+    pps_node, pps_kind = ref(rt_body, "postProcessStack")
+    if pps_node is not None:
+        pps_body = pps_node.components[pps_kind]
+
+        def stage(key):
+            n, k = ref(pps_body, key)
+            return (n.components[k] if n is not None else None)
+
+        cc_b, cg_b, bl_b, dof_b = stage("colorCorrection"), stage("colorGrading"), stage("bloom"), stage("dof")
+        cc = cg = bl = None
+        if cc_b is not None:
+            cc = host.ColorCorrection(float(cc_b.get("brightness", 0.96)), float(cc_b.get("saturation", 1.33)), float(cc_b.get("contrast", 1.85)),
+                                      enabled=bool(cc_b.get("m_Enabled", 1)))
+        if cg_b is not None:
+            lut_path = proj.by_guid.get((cg_b.get("lutTex") or {}).get("guid"))
+            lut = None
+            if lut_path:
+                from . import png
+                lut = png.read_texture(lut_path)
+            cg = host.ColorGrading(lutTex=lut, enabled=bool(cg_b.get("m_Enabled", 1)))
+        if bl_b is not None:
+            bl = host.Bloom(float(bl_b.get("luminanceThreshold", 1.0)), int(bl_b.get("downSampleStep", 7)), int(bl_b.get("downSampleBlurSize", 5)),
+                            float(bl_b.get("downSampleBlurSigma", 1.0)), int(bl_b.get("upSampleBlurSize", 5)),
+                            float(bl_b.get("upSampleBlurSigma", 1.0)), float(bl_b.get("bloomIntensity", 1.0)), enabled=bool(bl_b.get("m_Enabled", 1)))
+        dof = None
+        if dof_b is not None:
+            dof = host.DepthOfField(enabled=bool(dof_b.get("m_Enabled", 1)), focalLength=float(dof_b.get("focalLength", 1.0)),
+                                    lensRadius=float(dof_b.get("lensRadius", 0.1)))
+            rt.depthOfField = dof
+        rt.postProcessStack = host.PostProcessStack(cc, cg, bl, dof)
+    rt.enablePostProcess = bool(rt_body.get("enablePostProcess", 0)) and rt.postProcessStack is not None
     sky_guid = (rt_body.get("skyboxMat") or {}).get("guid")
     settings = {"samplingType": rt.samplingType, "skyboxMat": proj.by_guid.get(sky_guid), "n_renderers": len(renderers)}
     if sky_guid and proj.by_guid.get(sky_guid):

@@ -121,6 +121,32 @@ def box_mesh():
                                 np.array(tris, np.uint32)))
 
 
+def cylinder_mesh(segments=20, radius=0.5, half_height=1.0):
+    """A cylinder with the dimensions of Unity's built-in Cylinder (radius 0.5, height 2, 20 sides): a smooth-shaded
+    side and two flat caps.  The exact vertex layout of the built-in asset is not reproduced."""
+    ang = np.arange(segments + 1, dtype=np.float64) / segments * 2 * np.pi
+    cx, cz = np.cos(ang), np.sin(ang)
+    ps, ns, uvs, tris = [], [], [], []
+    for j in range(segments + 1):                                   # side: two rings
+        for y in (-half_height, half_height):
+            ps.append((radius * cx[j], y, radius * cz[j]))
+            ns.append((cx[j], 0.0, cz[j]))
+            uvs.append((j / segments, (y + half_height) / (2 * half_height)))
+    for j in range(segments):
+        a = 2 * j
+        tris += [(a, a + 1, a + 2), (a + 1, a + 3, a + 2)]
+    for y, ny in ((-half_height, -1.0), (half_height, 1.0)):        # caps: fans round a centre vertex
+        centre = len(ps)
+        ps.append((0.0, y, 0.0)); ns.append((0.0, ny, 0.0)); uvs.append((0.5, 0.5))
+        for j in range(segments + 1):
+            ps.append((radius * cx[j], y, radius * cz[j])); ns.append((0.0, ny, 0.0)); uvs.append((0.5 + 0.5 * cx[j], 0.5 + 0.5 * cz[j]))
+        for j in range(segments):
+            tris.append((centre, centre + 1 + j, centre + 2 + j))
+    n = len(ps)
+    return _ensure_outward(Mesh(np.array(ps, F32), np.array(ns, F32), np.tile(np.array([1, 0, 0], F32), (n, 1)), np.array(uvs, F32),
+                                np.array(tris, np.uint32)))
+
+
 def _ensure_outward(mesh):
     """Orient every triangle so that cross(e1, e2) points along the vertex
     normals: IntersectTriangle_MT97 culls det = d . cross(e2, e1) < EPSILON, so

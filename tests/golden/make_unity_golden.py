@@ -11,6 +11,9 @@
                                the same for Assets/Scenes/Chapter6_4.unity (20 sphere lights over five plates, MIS.png)
                                and Chapter6_2.unity (LightSampling.png)
 
+  unity_chapter7_5_1_scene.npz, reference_bloom1_blocks.npy
+                               Assets/Scenes/Chapter7_5_1.unity with the parameters of its Bloom component, and bloom1.png,
+                               the image published of it with that post-process stage on
   unity_chapter3_4_primitives.npz, unity_chapter4_1_primitives.npz
                                the buffers MeshCollector.Init would upload for two scenes that run with useBVH = false
                                (planes / spheres / cubes; Chapter4_1 adds five custom meshes, 13444 triangles),
@@ -38,14 +41,19 @@ def blocks_of(name):
     return ref[:h // K * K, :w // K * K].reshape(h // K, K, w // K, K, 3).mean((1, 3)).astype(np.float32), w, h
 
 
-def export(scene, out, w, h):
+def export(scene, out, w, h, with_bloom=False):
     ls = unity.load_scene(os.path.join(root, "Assets/Scenes", scene), root, w, h)
     rt = ls.rayTracing
+    extra = {}
+    if with_bloom:                                   # the scene's own Bloom component (the only enabled stage of its stack)
+        st = rt.postProcessStack
+        assert st.bloom.enabled and not st.colorCorrection.enabled and not st.colorGrading.enabled and st.dof is None
+        extra["bloom"] = np.frombuffer(bytes(st.bloom.Parameters()), np.uint8)
     (v, i, mi, sh), mats = rt.bvh.InitMesh()
     sph, area, disc = rt.lightImportanceSampling.Lights()
     np.savez_compressed(os.path.join(HERE, out), vertices=v, indices=i, material_index=mi, shadow_index=sh,
                         materials=np.array([m.MaterialData() for m in mats], wire.MATERIAL), sphere_lights=sph, area_lights=area,
-                        disc_lights=disc, params=np.frombuffer(bytes(rt.BuildParameters()), np.uint8))
+                        disc_lights=disc, params=np.frombuffer(bytes(rt.BuildParameters()), np.uint8), **extra)
     print(f"{scene}: {len(mi)} triangles, {len(mats)} materials, {len(sph)}/{len(area)}/{len(disc)} lights -> {out}")
 
 
@@ -59,6 +67,12 @@ for name, scene in (("MIS", "Chapter6_4"), ("LightSampling", "Chapter6_2")):
     b, w, h = blocks_of(name + ".png")
     np.save(os.path.join(HERE, f"reference_{name.lower()}_blocks.npy"), b)
     export(scene + ".unity", f"unity_{scene.lower()}_scene.npz", w, h)
+
+# Chapter7_5_1: a teapot behind a row of pillars in front of a long emissive quad; bloom1.png is that scene WITH its bloom
+# stage (threshold 0.001, 7 steps, sigma 0.05, intensity 0.02)
+b, w, h = blocks_of("bloom1.png")
+np.save(os.path.join(HERE, "reference_bloom1_blocks.npy"), b)
+export("Chapter7_5_1.unity", "unity_chapter7_5_1_scene.npz", w, h, with_bloom=True)
 
 
 def export_primitives(scene, out, w, h):

@@ -321,3 +321,47 @@ def test_reference_scene_reproduces_the_published_image(core, scene, image, medi
     if scene == "chapter6_3":
         walls = d[:26, :45]                               # left wall, ceiling, back wall, tall box: no sky in sight
         assert walls.mean() <= 3 and (walls <= 8).mean() >= 0.98
+
+
+def test_published_image_with_the_bloom_stage(core):
+    """Assets/Scenes/Chapter7_5_1.unity (a teapot behind pillars in front of a long emissive quad) and bloom1.png, the
+    image published of it WITH the scene's bloom stage on (threshold 0.001, 7 steps, sigma 0.05, intensity 0.02; the
+    parameters travel in the fixture).  With sigma 0.05 every Gaussian tap but the centre one has weight exp(-200) = 0,
+    so the shaders' frame-wide tap spacing (`_MainTex_ST.xy`) cannot matter and the stage is the sum of the bilinear
+    mip pyramid, ACES, gamma -- a veil of light over the whole frame.  The published HDRI is unknown (none is used
+    here: the window is the only light), so the anchor is coarse: with the stage the frame is within 20 counts of the
+    published one in the median, without it more than twice as far and 50 counts too dark."""
+    import os
+    from raytracing_amd.ingest import png
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(golden, "unity_chapter7_5_1_scene.npz"))
+    want = np.load(os.path.join(golden, "reference_bloom1_blocks.npy")).astype(np.float64)
+    p = wire.RtParams.from_buffer_copy(z["params"].tobytes())
+    bloom = wire.RtBloomParams.from_buffer_copy(z["bloom"].tobytes())
+    assert abs(bloom.downSampleBlurSigma - 0.05) < 1e-6 and bloom.downSampleStep == 7 and abs(bloom.bloomIntensity - 0.02) < 1e-6
+    sc = scenes.Scene("chapter7_5_1", z["vertices"], z["indices"], z["material_index"], z["shadow_index"], z["materials"],
+                      z["sphere_lights"], z["area_lights"], z["disc_lights"], None, p)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(p)
+    core.set_dirty()
+    core.render_frames(scenes.frame_seeds(256, 1))
+    k = 16
+
+    def blocks(img):
+        got = png.linear_to_srgb8(img[::-1, :, :3]).astype(np.float64)
+        return got[:want.shape[0] * k, :want.shape[1] * k].reshape(want.shape[0], k, want.shape[1], k, 3).mean((1, 3))
+
+    plain = blocks(core.readback(wire.IMAGE_CONVERGED))
+    core.post_bloom(wire.IMAGE_CONVERGED, bloom)
+    staged = blocks(core.readback(wire.IMAGE_POSTPROCESS))
+    d_plain, d_staged = np.abs(plain - want).max(-1), np.abs(staged - want).max(-1)
+    print(f"\nchapter7_5_1 vs published bloom1: median block difference {np.median(d_staged):.1f} with the bloom stage, "
+          f"{np.median(d_plain):.1f} without; mean offset {np.mean(staged - want):+.1f} / {np.mean(plain - want):+.1f}")
+    assert np.median(d_staged) <= 20 and np.median(d_plain) >= 2 * np.median(d_staged)
+    assert np.mean(plain - want) < -35 and abs(np.mean(staged - want)) < 25
+    # the same stage with texel-spaced taps gives the same frame: at this sigma only the centre tap counts
+    bloom.mainTexST[0], bloom.mainTexST[1] = 1.0 / p.width, 1.0 / p.height
+    first = core.readback(wire.IMAGE_POSTPROCESS)
+    core.post_bloom(wire.IMAGE_CONVERGED, bloom)
+    assert core.readback(wire.IMAGE_POSTPROCESS).tobytes() == first.tobytes()

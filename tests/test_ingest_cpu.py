@@ -357,3 +357,31 @@ def test_scenes_without_bvh_load_through_the_mesh_collector():
     assert p.n_triangles == 13444 and len(p.meshes) == 5
     # inactive spheres / cubes leave one zeroed element each (MeshCollector.cs:299-300)
     assert len(p.spheres) == 1 and not p.spheres.view(np.uint8).any()
+
+
+@needs_reference
+def test_post_process_stack_and_builtin_cylinders_are_read():
+    ls = unity.load_scene(f"{REF}/Assets/Scenes/Chapter7_5_1.unity", REF, 1096, 685)
+    rt = ls.rayTracing
+    st = rt.postProcessStack
+    assert rt.enablePostProcess is False                       # as saved; the published bloom1.png had it on
+    assert st.bloom.enabled and not st.colorCorrection.enabled and not st.colorGrading.enabled and st.dof is None
+    b = st.bloom.Parameters()
+    assert (b.downSampleStep, b.downSampleBlurSize, b.upSampleBlurSize) == (7, 5, 5)
+    assert abs(b.luminanceThreshold - 0.001) < 1e-9 and abs(b.downSampleBlurSigma - 0.05) < 1e-7 and abs(b.bloomIntensity - 0.02) < 1e-8
+    z = np.load(os.path.join(GOLDEN, "unity_chapter7_5_1_scene.npz"))
+    assert bytes(b) == z["bloom"].tobytes()
+    active = [m for m in rt.bvh.meshParent if m.enabled and m.activeInHierarchy]
+    assert sum(1 for m in active if getattr(m, "name", "").startswith("Cylinder")) == 9
+    (v, i, mi, sh), mats = rt.bvh.InitMesh()
+    assert len(mi) == 17620 and v.tobytes() == z["vertices"].tobytes()
+
+
+def test_cylinder_mesh_is_closed_and_outward():
+    m = scenes.cylinder_mesh(20)
+    p, t = m.positions.astype(np.float64), m.triangles
+    assert len(t) == 80 and np.allclose(np.hypot(p[:, 0], p[:, 2])[np.abs(m.normals[:, 1]) < 0.5], 0.5, atol=1e-6)
+    fn = np.cross(p[t[:, 1]] - p[t[:, 0]], p[t[:, 2]] - p[t[:, 0]])
+    centroid = p[t].mean(1)
+    assert ((fn * centroid).sum(1) > 0).all()                  # every face looks away from the axis centre
+    assert abs(np.abs(fn).sum() and np.linalg.norm(fn, axis=1).sum() / 2 - (2 * np.pi * 0.5 * 2 + 2 * np.pi * 0.25)) < 0.1
