@@ -6,14 +6,14 @@
 // Structure follows the reference: a fragment function per shader, drawn over every
 // destination pixel by Blit() the way Graphics.Blit draws a full-screen quad.
 //
-// Parity unpinned: the reference holds no test, golden image or known-answer vector
-// for this chain (its published images were saved from convergedRT, before the chain,
-// SaveTexture.cs:17-20), the samplers are fixed-function hardware and
-// LinearToGammaSpace / GammaToLinearSpace live in Unity's UnityCG.cginc (Unity
-// 2021.3.1f1 built-in shaders, not in the reference tree; restated in
-// include/rt_post.h from their published text).  What IS anchored on the reference's
-// own data: grading through its NeutralLUT_32.png must be the identity up to the
-// LUT's resolution (tests/test_post_cpu.py).
+// Parity unpinned for exact values: the reference holds no test or known-answer vector for this
+// chain, the samplers are fixed-function hardware and LinearToGammaSpace / GammaToLinearSpace
+// live in Unity's UnityCG.cginc (Unity 2021.3.1f1 built-in shaders, not in the reference tree;
+// restated in include/rt_post.h from their published text).  What IS anchored on the
+// reference's own data: grading through its NeutralLUT_32.png must be the identity up to the
+// LUT's resolution (tests/test_post_cpu.py), and Assets/Outputs/bloom1.png, published of
+// Assets/Scenes/Chapter7_5_1.unity with that scene's Bloom component on, is matched to a median
+// of 15 / 255 per 16 x 16 block with the stage and 46 without (tests/test_gpu_scale.py).
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
