@@ -376,13 +376,28 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *                          (measured 3 % slower: the walkers already fill the chip)
  *   RT_OPT_BATCH_FRAMES    1..64 frames rt_render_frames keeps in flight; 0 (default): as many as give
  *                          up to 128 M paths per launch (64 for a whole 1080p frame, 16 for a 4K frame; 164 bytes of
- *                          device memory per path, halved until it fits) */
+ *                          device memory per path, halved until it fits)
+ *   RT_OPT_OVERLAP_SHADOW  1 (default): in rt_render_frames, when the ShadowMap pass shares CSMain's primary hits, its rays
+ *                          are walked WHILE the later bounces run: one launch on a stream masked to all compute units but
+ *                          a few, the remaining bounce and shading launches on a stream masked to those few, a last launch
+ *                          that drains the same queue afterwards.  Same results bit for bit (a ray's result does not
+ *                          depend on which launch walks it); 2 % faster for a whole 1080p image of the car scene, 10 %
+ *                          for an eighth of it.  Off while counters or kernel timing are enabled (they report launches
+ *                          one by one), with RT_OPT_PACKET_SHADOW, RT_OPT_TWO_STREAMS or the brute-force flag, and where
+ *                          the runtime cannot make masked streams.
+ *   RT_OPT_OVERLAP_AFTER   0..6, default 1: the bounce whose extend launch the overlap starts after
+ *   RT_OPT_OVERLAP_CUS     compute units the bounce launches keep meanwhile, default 32 (multiples of 32 measured best);
+ *                          read when a context first renders that way, and the contexts of a process that render on the
+ *                          same device share the first one's split */
 #define RT_OPT_PACKET_SHADOW 0
 #define RT_OPT_PACKET_PRIMARY 1
 #define RT_OPT_PACKET_TRACE 2
 #define RT_OPT_BATCH_FRAMES 3
 #define RT_OPT_MATERIAL_SORT 4
 #define RT_OPT_TWO_STREAMS 5
+#define RT_OPT_OVERLAP_SHADOW 6
+#define RT_OPT_OVERLAP_AFTER 7
+#define RT_OPT_OVERLAP_CUS 8
 int rt_set_option(RtContext *ctx, int option, int value);
 
 /* ------------------------------------------------------------------- stats */

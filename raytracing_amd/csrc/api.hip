@@ -127,7 +127,7 @@ int rt_create(int device_id, RtContext **out_ctx)
         hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void **)&ctx->dStats, 64 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&ctx->dErrorFlag, 4) != hipSuccess || hipMalloc((void **)&ctx->dQCount, RT_COUNTER_BLOCK_WORDS * 4) != hipSuccess ||
-        hipMalloc((void **)&ctx->dStackSpill, (size_t)ctx->numCU * RT_SPILL_WORDS_PER_CU * 4) != hipSuccess) {
+        hipMalloc((void **)&ctx->dStackSpill, (size_t)RT_SPILL_AREAS * ctx->numCU * RT_SPILL_WORDS_PER_CU * 4) != hipSuccess) {
         delete ctx;
         return RT_E_DEVICE;
     }
@@ -154,6 +154,7 @@ int rt_destroy(RtContext *ctx)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2), (void)hipStreamDestroy(ctx->stream2);
+    rt_release_overlap_streams(ctx);
     if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
     if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -531,6 +532,15 @@ int rt_set_option(RtContext *ctx, int option, int value)
     case RT_OPT_PACKET_TRACE: ctx->optPacketTrace = value != 0; return RT_OK;
     case RT_OPT_MATERIAL_SORT: ctx->optMaterialSort = value != 0; return RT_OK;
     case RT_OPT_TWO_STREAMS: ctx->optTwoStreams = value != 0; return RT_OK;
+    case RT_OPT_OVERLAP_SHADOW: ctx->optOverlapShadow = value != 0; return RT_OK;
+    case RT_OPT_OVERLAP_AFTER:
+        if (value < 0 || value > 6) return rt_fail(ctx, RT_E_INVALID, "RT_OPT_OVERLAP_AFTER must be 0..6");
+        ctx->optOverlapAfter = (uint32_t)value;
+        return RT_OK;
+    case RT_OPT_OVERLAP_CUS:
+        if (value < 1 || value >= ctx->numCU) return rt_fail(ctx, RT_E_INVALID, "RT_OPT_OVERLAP_CUS must be 1..compute units - 1");
+        ctx->optOverlapCUs = (uint32_t)value;
+        return RT_OK;
     case RT_OPT_BATCH_FRAMES:
         if (value < 0 || value > 64) return rt_fail(ctx, RT_E_INVALID, "RT_OPT_BATCH_FRAMES must be 0..64");
         ctx->optBatchFrames = (uint32_t)value;

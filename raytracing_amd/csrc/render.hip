@@ -124,6 +124,11 @@ struct ShadowSrc {
     }
 };
 
+// The same rays as a type of its own: launches of it share the chip with the bounce launches and two of
+// them drain one queue (launch_shadow_overlapped), so their durations in a kernel trace say nothing about
+// the walker by itself; they are listed apart from k_traverse<ShadowSrc>'s.
+struct ShadowSrcOverlapped : ShadowSrc {};
+
 template <bool COUNT, class Src>
 __global__ __launch_bounds__(TRV_THREADS) void k_traverse(RtSceneView sv, Src src, uint32_t *__restrict__ cursor)
 {
@@ -574,15 +579,18 @@ RtSceneView rt_scene_view(RtContext *ctx)
 
 // Layout of the small counter block (dQCount), zeroed at the start of a batch:
 //   [0..8]  live-path counts of bounce 0..8      [9]  shaded pixels of the ShadowMap pass, [10] its primary rays
-//   [16..23] ray cursors of the 8 extend launches, [24]/[25] ShadowMap primary / shadow rays, [26] rt_trace_rays
+//   [32..39] ray cursors of the 8 extend launches, [40]/[41] ShadowMap primary / shadow rays, [42] rt_trace_rays
+// The cursors have a 128-byte line to themselves: a line that thousands of waves update with atomics answers
+// plain reads very slowly (a ray source that read its queue count from the cursors' line on every refill
+// walked its rays 15 times slower).
 #define CNT_SMQ 9
 #define CNT_SMPRIM 10
-#define CNT_FETCH 16
-#define CNT_FETCH_SM0 24
-#define CNT_FETCH_SM1 25
-#define CNT_FETCH_TRACE 26
-#define CNT_WORDS 32
-static_assert(CNT_WORDS <= RT_COUNTER_BLOCK_WORDS, "counter block too small");
+#define CNT_FETCH 32
+#define CNT_FETCH_SM0 40
+#define CNT_FETCH_SM1 41
+#define CNT_FETCH_TRACE 42
+#define CNT_WORDS 64
+static_assert(2 * CNT_WORDS <= RT_COUNTER_BLOCK_WORDS, "counter block too small");   // one per stream
 #define RT_MAX_BATCH 64u
 #define RT_BATCH_PATH_SLOTS (1u << 27)   // frames in flight are chosen so that a launch covers up to this many paths (164 B each: 22 GB)
 
@@ -714,11 +722,8 @@ static void launch_sm_setup(RtContext *ctx, const RtSceneView &sv, uint32_t tota
     rt_timer_end(ctx);
 }
 
-// 16 shadow rays per shaded pixel + the running mean (needs dSmQueue / dSmRec filled by k_sm_setup).
-static void launch_shadow_rays(RtContext *ctx, const RtSceneView &sceneView, uint32_t total)
+static ShadowSrc shadow_source(RtContext *ctx)
 {
-    RtSceneView sv = sceneView;
-    sv.stats = ctx->dStats + 32;                 // counted apart from the other traversals
     const RtParams &P = ctx->params;
     ShadowSrc sh;
     sh.smq = ctx->dSmQueue;
@@ -731,17 +736,156 @@ static void launch_shadow_rays(RtContext *ctx, const RtSceneView &sceneView, uin
     sh.lightTangent = rt_normalize3(rt_cross3(sh.lightDir, rt_mk3(0.0f, 1.0f, 0.0f)));
     sh.lightBitangent = rt_normalize3(rt_cross3(sh.lightTangent, sh.lightDir));
     sh.lightRadius = P.lightParameter[3];
-    if (ctx->optPacketShadow) launch_traverse_packets(ctx, sv, sh, ctx->dQCount + CNT_FETCH_SM1, total * 16u, "k_shadow_rays");
-    else launch_traverse(ctx, sv, sh, ctx->dQCount + CNT_FETCH_SM1, total * 16u, "k_shadow_rays");
+    return sh;
+}
+
+static void launch_sm_resolve(RtContext *ctx, uint32_t total)
+{
     rt_timer_begin(ctx, "k_sm_resolve");
-    hipLaunchKernelGGL(k_sm_resolve, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, P, ctx->dSmQueue, ctx->dQCount + CNT_SMQ,
+    hipLaunchKernelGGL(k_sm_resolve, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, ctx->params, ctx->dSmQueue, ctx->dQCount + CNT_SMQ,
                        ctx->dSmRec, ctx->dSmFlags, ctx->dShadowMap);
     rt_timer_end(ctx);
 }
 
+// 16 shadow rays per shaded pixel + the running mean (needs dSmQueue / dSmRec filled by k_sm_setup).
+static void launch_shadow_rays(RtContext *ctx, const RtSceneView &sceneView, uint32_t total)
+{
+    RtSceneView sv = sceneView;
+    sv.stats = ctx->dStats + 32;                 // counted apart from the other traversals
+    const ShadowSrc sh = shadow_source(ctx);
+    if (ctx->optPacketShadow) launch_traverse_packets(ctx, sv, sh, ctx->dQCount + CNT_FETCH_SM1, total * 16u, "k_shadow_rays");
+    else launch_traverse(ctx, sv, sh, ctx->dQCount + CNT_FETCH_SM1, total * 16u, "k_shadow_rays");
+    launch_sm_resolve(ctx, total);
+}
+
+// ---- shadow rays walked while the later bounces run
+// A bounce launch lasts at least as long as its longest ray, a chain of dependent node fetches (0.5 ms on
+// the car scene), and from the third bounce on it holds few rays: most of the chip idles through it.  The
+// shadow rays depend on the primary hits only.  So, once the second bounce's rays are walked:
+//   - a first shadow launch goes to a stream whose queue may use all compute units but a few, with
+//     exactly as many blocks as fit there (the walker's blocks stay until the queue is empty);
+//   - the remaining bounce and shading launches go to a stream that may use only those few units;
+//   - after the last bounce a second shadow launch on the main stream drains the same queue through the
+//     same cursor from the units the bounces had.  Which launch walks a ray does not matter to its result.
+// The units are split by queue masks, not by leaving slots free: blocks of kernels with different register
+// and LDS footprints that come and go among the walker's long-lived blocks fragment a unit's register
+// file (a 128-register hole takes one 88-register wave and wastes the rest), which cost the walker a
+// fifth of its waves and starved the shading kernel outright when tried.
+static uint32_t walker_blocks_per_cu()
+{
+    static int perCU = 0;
+    if (perCU == 0) {
+        int n = 0;
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_traverse<false, ShadowSrcOverlapped>, TRV_THREADS, 0);
+        perCU = (e == hipSuccess && n > 0) ? n : 4;
+    }
+    return (uint32_t)perCU;
+}
+
+// The two masked queues of a device are shared by the contexts of the process that render on it and go
+// when the last of those contexts is destroyed; the split is the one the first of them asked for.
+struct RtMaskedStreams {
+    uint32_t few = 0, users = 0;
+    hipStream_t shadow = nullptr, chain = nullptr;
+};
+static std::mutex g_maskedMutex;
+static std::map<int, RtMaskedStreams> g_masked;
+
+static bool overlap_streams_ready(RtContext *ctx)
+{
+    if (ctx->overlapTried) return ctx->overlapCUs != 0;
+    ctx->overlapTried = true;
+    std::lock_guard<std::mutex> lock(g_maskedMutex);
+    RtMaskedStreams &m = g_masked[ctx->device];
+    if (m.users == 0) {
+        const uint32_t n = (uint32_t)ctx->numCU;
+        const uint32_t few = ctx->optOverlapCUs;
+        if (few < 1 || few >= n) return false;
+        const uint32_t words = (n + 31u) / 32u;
+        std::vector<uint32_t> most(words, 0u), rest(words, 0u);
+        for (uint32_t cu = 0; cu < n; ++cu) (cu < n - few ? most : rest)[cu >> 5] |= 1u << (cu & 31u);
+        if (hipExtStreamCreateWithCUMask(&m.shadow, words, most.data()) != hipSuccess ||
+            hipExtStreamCreateWithCUMask(&m.chain, words, rest.data()) != hipSuccess) {
+            (void)hipGetLastError();             // no masked queues here: the plain order is used
+            if (m.shadow) (void)hipStreamDestroy(m.shadow);
+            m.shadow = m.chain = nullptr;
+            return false;
+        }
+        m.few = few;
+    }
+    m.users += 1;
+    ctx->streamShadow = m.shadow;
+    ctx->streamChain = m.chain;
+    ctx->overlapCUs = m.few;
+    return true;
+}
+
+void rt_release_overlap_streams(RtContext *ctx)
+{
+    if (!ctx->overlapCUs) return;
+    std::lock_guard<std::mutex> lock(g_maskedMutex);
+    RtMaskedStreams &m = g_masked[ctx->device];
+    (void)hipStreamSynchronize(m.shadow);
+    (void)hipStreamSynchronize(m.chain);
+    if (--m.users == 0) {
+        (void)hipStreamDestroy(m.shadow);
+        (void)hipStreamDestroy(m.chain);
+        m = RtMaskedStreams();
+    }
+    ctx->streamShadow = ctx->streamChain = nullptr;
+    ctx->overlapCUs = 0;
+}
+
+// Called right after the extend launch of the bounce the overlap starts at; from here on ctx->stream is the
+// chain stream (overlap_join puts the main stream back).
+static int overlap_fork(RtContext *ctx, const RtSceneView &sceneView, uint32_t total)
+{
+    RtSceneView sv = sceneView;
+    sv.stats = ctx->dStats + 32;
+    sv.stackSpill = ctx->dStackSpill + (size_t)ctx->numCU * RT_SPILL_WORDS_PER_CU;     // the second spill area
+    ShadowSrcOverlapped sh;
+    static_cast<ShadowSrc &>(sh) = shadow_source(ctx);
+    RT_HIP(ctx, hipEventRecord(ctx->evFork, ctx->stream));
+    RT_HIP(ctx, hipStreamWaitEvent(ctx->streamShadow, ctx->evFork, 0));
+    RT_HIP(ctx, hipStreamWaitEvent(ctx->streamChain, ctx->evFork, 0));
+    uint32_t blocks = ((uint32_t)ctx->numCU - ctx->overlapCUs) * walker_blocks_per_cu();
+    const uint32_t need = (total * 16u + TRV_THREADS - 1) / TRV_THREADS;
+    if (need < blocks) blocks = need ? need : 1;
+    if (ctx->countersOn) hipLaunchKernelGGL((k_traverse<true, ShadowSrcOverlapped>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->streamShadow, sv, sh, ctx->dQCount + CNT_FETCH_SM1);
+    else hipLaunchKernelGGL((k_traverse<false, ShadowSrcOverlapped>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->streamShadow, sv, sh, ctx->dQCount + CNT_FETCH_SM1);
+    RT_HIP(ctx, hipEventRecord(ctx->evJoin, ctx->streamShadow));
+    ctx->streamMain = ctx->stream;
+    ctx->stream = ctx->streamChain;
+    return RT_OK;
+}
+
+// After the last bounce: back to the main stream, which helps with the shadow rays from the units the bounces had.
+static int overlap_join(RtContext *ctx, const RtSceneView &sceneView, uint32_t total)
+{
+    hipStream_t chain = ctx->stream;
+    ctx->stream = ctx->streamMain;
+    ctx->streamMain = nullptr;
+    RT_HIP(ctx, hipEventRecord(ctx->evFork, chain));
+    RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evFork, 0));
+    RtSceneView sv = sceneView;
+    sv.stats = ctx->dStats + 32;
+    ShadowSrcOverlapped sh;
+    static_cast<ShadowSrc &>(sh) = shadow_source(ctx);
+    uint32_t blocks = ctx->overlapCUs * walker_blocks_per_cu();
+    const uint32_t need = (total * 16u + TRV_THREADS - 1) / TRV_THREADS;
+    if (need < blocks) blocks = need ? need : 1;
+    if (ctx->countersOn) hipLaunchKernelGGL((k_traverse<true, ShadowSrcOverlapped>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, sh, ctx->dQCount + CNT_FETCH_SM1);
+    else hipLaunchKernelGGL((k_traverse<false, ShadowSrcOverlapped>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, sh, ctx->dQCount + CNT_FETCH_SM1);
+    RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evJoin, 0));
+    launch_sm_resolve(ctx, total);
+    return RT_OK;
+}
+
 // CSMain for `frames` frames of the current view (seeds already in dSeeds).
 // withShadowSetup: also prepare the ShadowMap pass from CSMain's own primary hits.
-static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup)
+// overlapAfter >= 0 (needs withShadowSetup): the shadow rays start after the extend launch of that bounce
+// (overlap_fork); the caller then ends with overlap_join instead of launch_shadow_rays.
+static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup, int overlapAfter = -1)
 {
     const uint32_t n = ctx->tile.nSlots;
     if (n == 0) return RT_OK;
@@ -770,6 +914,11 @@ static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup
         } else if (b == 0 && ctx->optPacketPrimary) launch_traverse_packets(ctx, sv, src, ctx->dQCount + CNT_FETCH + b, total, "k_extend");
         else launch_traverse(ctx, sv, src, ctx->dQCount + CNT_FETCH + b, total, "k_extend");
         if (b == 0 && withShadowSetup) launch_sm_setup(ctx, sv, total, qin, ctx->dQCount);   // before shade moves the rays on
+        if (b == overlapAfter) {
+            const int rc = overlap_fork(ctx, sv, total);
+            if (rc) return rc;
+            st = ctx->stream;
+        }
         rt_timer_begin(ctx, "k_shade");
         if (brute)
             hipLaunchKernelGGL((k_shade<false, true>), grid, blk, 0, st, sv, ctx->brute, ctx->tile, ctx->params, b, qin, ctx->dQCount + b, qout,
@@ -889,12 +1038,23 @@ struct RtLaneScope {
 
 static int render_lane(RtContext *ctx, uint32_t frames, bool matte, bool shared)
 {
-    int rc = dispatch_frames(ctx, frames, shared);
-    if (rc) return rc;
-    if (matte) {
-        if (shared) launch_shadow_rays(ctx, rt_scene_view(ctx), ctx->tile.nSlots * frames);
-        else rc = shadowmap_frames(ctx, frames);
+    // Per-launch counters and event timers describe launches of one stream, one after the other: both keep the plain order.
+    int overlapAfter = -1;
+    if (shared && ctx->optOverlapShadow && !ctx->optTwoStreams && !ctx->countersOn && !ctx->timingOn && !ctx->optPacketShadow &&
+        !(ctx->params.flags & RT_FLAG_BRUTE_FORCE) && ctx->tile.nSlots != 0 && ctx->optOverlapAfter + 1 < RT_MAX_BOUNCE &&
+        overlap_streams_ready(ctx))
+        overlapAfter = (int)ctx->optOverlapAfter;
+    int rc = dispatch_frames(ctx, frames, shared, overlapAfter);
+    if (rc || !matte) {
+        if (ctx->streamMain) {                   // left the bounce loop on the chain stream
+            ctx->stream = ctx->streamMain;
+            ctx->streamMain = nullptr;
+        }
+        return rc;
     }
+    if (overlapAfter >= 0) return overlap_join(ctx, rt_scene_view(ctx), ctx->tile.nSlots * frames);
+    if (shared) launch_shadow_rays(ctx, rt_scene_view(ctx), ctx->tile.nSlots * frames);
+    else rc = shadowmap_frames(ctx, frames);
     return rc;
 }
 
@@ -920,7 +1080,7 @@ int rt_render_frames_impl(RtContext *ctx, const float *seeds, uint32_t nFrames)
             RT_HIP(ctx, hipEventRecord(ctx->evFork, ctx->stream));
             RT_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->evFork, 0));
             {
-                RtLaneScope lane(ctx, ctx->stream2, fA, ctx->dQCount + 32);
+                RtLaneScope lane(ctx, ctx->stream2, fA, ctx->dQCount + CNT_WORDS);
                 rc = render_lane(ctx, fB, matte, shared);
             }
             if (rc) return rc;

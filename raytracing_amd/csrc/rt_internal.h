@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -133,8 +134,9 @@ struct RtPendingEvent {
     hipEvent_t start, stop;
 };
 
-#define RT_COUNTER_BLOCK_WORDS 64   // queue counts (dQCount)
+#define RT_COUNTER_BLOCK_WORDS 128  // queue counts and ray cursors (dQCount), one set per stream
 #define RT_SPILL_WORDS_PER_CU (2048 * RT_STACK_DEPTH)   // room for every stack level of 2048 lanes per CU
+#define RT_SPILL_AREAS 2                                // walker launches that may be on the chip together
 
 struct RtPostState;   // post.hip
 
@@ -143,6 +145,10 @@ struct RtContext {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;        // second half of the frames in flight (rt_render_frames)
     hipEvent_t evFork = nullptr, evJoin = nullptr;
+    hipStream_t streamShadow = nullptr, streamChain = nullptr;   // queues masked to most / the remaining few compute units (process-wide)
+    hipStream_t streamMain = nullptr;     // the caller's stream while ctx->stream is the chain stream
+    uint32_t overlapCUs = 0;              // the split the two masked streams were made for (0: none held)
+    bool overlapTried = false;
     std::string err;
 
     // inputs
@@ -199,6 +205,9 @@ struct RtContext {
     float *dSeeds = nullptr;              // per-frame seeds of the batch in flight
     bool optPacketShadow = false, optPacketPrimary = false, optPacketTrace = false;
     bool optMaterialSort = true, optTwoStreams = false;
+    bool optOverlapShadow = true;         // walk the shadow rays while the later bounces run (render.hip, overlap_fork)
+    uint32_t optOverlapAfter = 1;         // ... from the extend launch of this bounce on
+    uint32_t optOverlapCUs = 32;          // compute units the bounce launches keep meanwhile
     uint32_t optBatchFrames = 0;          // 0 = by path count (rt_batch_frames)
     uint32_t batchCap = 0;                // frames the path-state buffers can hold
     uint32_t lastFrame = 0;               // frame of the batch that RT_IMAGE_RT / RT_IMAGE_SHADOWMAP show
@@ -208,7 +217,7 @@ struct RtContext {
     uint32_t sampleCount = 0;
 
     // stats / timing
-    uint32_t *dStackSpill = nullptr;     // numCU * 8 blocks * 256 lanes * (RT_STACK_DEPTH - TRV_STACK_LDS) words
+    uint32_t *dStackSpill = nullptr;     // RT_SPILL_AREAS x numCU x RT_SPILL_WORDS_PER_CU words
     unsigned long long *dStats = nullptr; // 64 x u64: counters [0..4] / [32..36] (shadow rays), walker profile [16..25] / [48..57]
     uint32_t *dErrorFlag = nullptr;
     bool countersOn = false;
@@ -240,6 +249,7 @@ float4 *rt_image_ptr(RtContext *ctx, int which);   // tile-local device image be
 
 // brute.hip
 void rt_free_brute(RtContext *ctx);
+void rt_release_overlap_streams(RtContext *ctx);   // render.hip
 
 // post.hip
 void rt_free_post(RtContext *ctx);

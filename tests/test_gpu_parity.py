@@ -266,6 +266,31 @@ def test_packet_walkers_do_not_change_a_bit(core):
     assert (images[0][1][..., 0] < 1).any()
 
 
+def test_shadow_rays_walked_while_the_bounces_run_do_not_change_a_bit(core):
+    """From some bounce on the ShadowMap pass's rays are walked on most of the chip while the remaining bounces
+    run on the rest, and a second launch drains the same queue afterwards: whatever the bounce it starts
+    at, the images are those of the plain order."""
+    sc = scenes.car_standin(96, 64, detail=0.02)
+    seeds = scenes.frame_seeds(5, seed=12)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(sc.params)
+    images = []
+    for on, after in ((0, 1), (1, 1), (1, 0), (1, 6), (1, 3)):
+        core.set_option(wire.OPT_OVERLAP_SHADOW, on)
+        core.set_option(wire.OPT_OVERLAP_AFTER, after)
+        for _ in range(2):
+            core.set_dirty()
+            core.render_frames(seeds)
+        images.append((core.readback(wire.IMAGE_CONVERGED), core.readback(wire.IMAGE_SHADOWMAP)))
+    core.set_option(wire.OPT_OVERLAP_SHADOW, 1)
+    core.set_option(wire.OPT_OVERLAP_AFTER, 1)
+    assert (images[0][1][..., 0] < 1).any() and (images[0][1][..., 0] == 1).any()
+    for k in range(1, len(images)):
+        H.assert_bits_equal(images[0][0], images[k][0], f"converged image, overlap variant {k}")
+        H.assert_bits_equal(images[0][1], images[k][1], f"shadow map, overlap variant {k}")
+
+
 def test_tiles_union_is_bit_identical_to_whole_frame(core):
     sc = scenes.cornell_box(200, 136, sphere_segments=16)     # not a multiple of the tile size
     seeds = scenes.frame_seeds(2, seed=6)

@@ -13,9 +13,13 @@ summary = json.load(open(sys.argv[1]))
 bench = json.load(open(sys.argv[2]))
 out = {}
 for kname, v in summary.items():
-    if "k_traverse<" not in kname or "FETCH_SIZE" not in v:
+    # the plain (non-counting) instantiations only; k_traverse<false, ShadowSrcOverlapped> launches share the
+    # chip with other kernels in normal runs and are not the kernel by itself
+    if not kname.startswith("k_traverse<false, ") or "FETCH_SIZE" not in v:
         continue
-    src = "ShadowSrc" if "ShadowSrc" in kname else "QueueSrc" if "QueueSrc" in kname else "ArraySrc"
+    src = kname[len("k_traverse<false, "):].rstrip(">").strip()
+    if src not in ("ShadowSrc", "QueueSrc", "ArraySrc"):
+        continue
     n = v["_dispatches"]
     fetch = v["FETCH_SIZE"] * 1024.0 * 2.0
     write = v.get("WRITE_SIZE", 0.0) * 1024.0
