@@ -577,19 +577,21 @@ RtSceneView rt_scene_view(RtContext *ctx)
     return sv;
 }
 
-// Layout of the small counter block (dQCount), zeroed at the start of a batch:
-//   [0..8]  live-path counts of bounce 0..8      [9]  shaded pixels of the ShadowMap pass, [10] its primary rays
-//   [32..39] ray cursors of the 8 extend launches, [40]/[41] ShadowMap primary / shadow rays, [42] rt_trace_rays
-// The cursors have a 128-byte line to themselves: a line that thousands of waves update with atomics answers
-// plain reads very slowly (a ray source that read its queue count from the cursors' line on every refill
-// walked its rays 15 times slower).
-#define CNT_SMQ 9
-#define CNT_SMPRIM 10
-#define CNT_FETCH 32
-#define CNT_FETCH_SM0 40
-#define CNT_FETCH_SM1 41
-#define CNT_FETCH_TRACE 42
-#define CNT_WORDS 64
+// Layout of the counter block (dQCount), zeroed at the start of a batch.  Every counter has a 128-byte line
+// to itself: a line that thousands of waves update with atomics answers plain reads very slowly (a ray
+// source that read its queue count from the cursors' line on every refill walked its rays 15 times
+// slower), and launches that run at the same time would otherwise queue at one line for different cursors.
+//   lines 0..8  live-path counts of bounce 0..8     9 shaded pixels of the ShadowMap pass, 10 its primary rays
+//   lines 12..19 ray cursors of the 8 extend launches, 20 / 21 ShadowMap primary / shadow rays, 22 rt_trace_rays
+#define CNT_LINE 32
+#define CNT_Q(b) ((b) * CNT_LINE)
+#define CNT_SMQ (9 * CNT_LINE)
+#define CNT_SMPRIM (10 * CNT_LINE)
+#define CNT_CURSOR(b) ((12 + (b)) * CNT_LINE)
+#define CNT_FETCH_SM0 (20 * CNT_LINE)
+#define CNT_FETCH_SM1 (21 * CNT_LINE)
+#define CNT_FETCH_TRACE (22 * CNT_LINE)
+#define CNT_WORDS (24 * CNT_LINE)
 static_assert(2 * CNT_WORDS <= RT_COUNTER_BLOCK_WORDS, "counter block too small");   // one per stream
 #define RT_MAX_BATCH 64u
 #define RT_BATCH_PATH_SLOTS (1u << 27)   // frames in flight are chosen so that a launch covers up to this many paths (164 B each: 22 GB)
@@ -903,7 +905,7 @@ static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup
         uint32_t *qin = ctx->dQueue[b & 1], *qout = ctx->dQueue[(b + 1) & 1];
         QueueSrc src;
         src.queue = qin;
-        src.qcount = ctx->dQCount + b;
+        src.qcount = ctx->dQCount + CNT_Q(b);
         src.po = ctx->dPo;
         src.pd = ctx->dPd;
         src.hit = ctx->dHit;
@@ -911,8 +913,8 @@ static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup
             rt_timer_begin(ctx, "k_brute_extend");
             hipLaunchKernelGGL(k_brute_extend<QueueSrc>, dim3((total + 255) / 256), dim3(256), 0, st, ctx->brute, src, ctx->countersOn ? ctx->dStats : nullptr);
             rt_timer_end(ctx);
-        } else if (b == 0 && ctx->optPacketPrimary) launch_traverse_packets(ctx, sv, src, ctx->dQCount + CNT_FETCH + b, total, "k_extend");
-        else launch_traverse(ctx, sv, src, ctx->dQCount + CNT_FETCH + b, total, "k_extend");
+        } else if (b == 0 && ctx->optPacketPrimary) launch_traverse_packets(ctx, sv, src, ctx->dQCount + CNT_CURSOR(b), total, "k_extend");
+        else launch_traverse(ctx, sv, src, ctx->dQCount + CNT_CURSOR(b), total, "k_extend");
         if (b == 0 && withShadowSetup) launch_sm_setup(ctx, sv, total, qin, ctx->dQCount);   // before shade moves the rays on
         if (b == overlapAfter) {
             const int rc = overlap_fork(ctx, sv, total);
@@ -921,14 +923,14 @@ static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup
         }
         rt_timer_begin(ctx, "k_shade");
         if (brute)
-            hipLaunchKernelGGL((k_shade<false, true>), grid, blk, 0, st, sv, ctx->brute, ctx->tile, ctx->params, b, qin, ctx->dQCount + b, qout,
-                               ctx->dQCount + b + 1, ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
+            hipLaunchKernelGGL((k_shade<false, true>), grid, blk, 0, st, sv, ctx->brute, ctx->tile, ctx->params, b, qin, ctx->dQCount + CNT_Q(b), qout,
+                               ctx->dQCount + CNT_Q(b + 1), ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
         else if (ctx->optMaterialSort)
-            hipLaunchKernelGGL((k_shade<true, false>), grid, blk, 0, st, sv, ctx->brute, ctx->tile, ctx->params, b, qin, ctx->dQCount + b, qout,
-                               ctx->dQCount + b + 1, ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
+            hipLaunchKernelGGL((k_shade<true, false>), grid, blk, 0, st, sv, ctx->brute, ctx->tile, ctx->params, b, qin, ctx->dQCount + CNT_Q(b), qout,
+                               ctx->dQCount + CNT_Q(b + 1), ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
         else
-            hipLaunchKernelGGL((k_shade<false, false>), grid, blk, 0, st, sv, ctx->brute, ctx->tile, ctx->params, b, qin, ctx->dQCount + b, qout,
-                               ctx->dQCount + b + 1, ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
+            hipLaunchKernelGGL((k_shade<false, false>), grid, blk, 0, st, sv, ctx->brute, ctx->tile, ctx->params, b, qin, ctx->dQCount + CNT_Q(b), qout,
+                               ctx->dQCount + CNT_Q(b + 1), ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
         rt_timer_end(ctx);
     }
     ctx->lastFrame = frames - 1;
@@ -946,8 +948,8 @@ static int shadowmap_frames(RtContext *ctx, uint32_t frames)
     const RtSceneView sv = rt_scene_view(ctx);
     uint32_t *cnt = ctx->dQCount;
     // the path-state buffers of CSMain are free again at this point and are reused
-    RT_HIP(ctx, hipMemsetAsync(cnt + CNT_SMQ, 0, 2 * sizeof(uint32_t), st));
-    RT_HIP(ctx, hipMemsetAsync(cnt + CNT_FETCH_SM0, 0, 2 * sizeof(uint32_t), st));
+    RT_HIP(ctx, hipMemsetAsync(cnt + CNT_SMQ, 0, 2 * CNT_LINE * sizeof(uint32_t), st));          // CNT_SMQ and CNT_SMPRIM
+    RT_HIP(ctx, hipMemsetAsync(cnt + CNT_FETCH_SM0, 0, 2 * CNT_LINE * sizeof(uint32_t), st));    // both ShadowMap cursors
     rt_timer_begin(ctx, "k_sm_generate");
     hipLaunchKernelGGL((k_generate<RT_FLAG_DEPTH_OF_FIELD, false>), dim3((total + Q_TILE - 1) / Q_TILE), dim3(Q_THREADS), 0, st, ctx->tile, ctx->params,
                        ctx->dSeeds, frames, ctx->dPo, ctx->dPd, ctx->dPe, ctx->dShadowMap, ctx->dRng, ctx->dQueue[0], cnt + CNT_SMPRIM);

@@ -134,7 +134,7 @@ struct RtPendingEvent {
     hipEvent_t start, stop;
 };
 
-#define RT_COUNTER_BLOCK_WORDS 128  // queue counts and ray cursors (dQCount), one set per stream
+#define RT_COUNTER_BLOCK_WORDS 1536 // queue counts and ray cursors (dQCount), a 128-byte line each, one set per stream
 #define RT_SPILL_WORDS_PER_CU (2048 * RT_STACK_DEPTH)   // room for every stack level of 2048 lanes per CU
 #define RT_SPILL_AREAS 2                                // walker launches that may be on the chip together
 
