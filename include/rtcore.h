@@ -377,6 +377,9 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *   RT_OPT_BATCH_FRAMES    1..64 frames rt_render_frames keeps in flight; 0 (default): as many as give
  *                          up to 128 M paths per launch (64 for a whole 1080p frame, 16 for a 4K frame; 164 bytes of
  *                          device memory per path, halved until it fits)
+ *   RT_OPT_FIRST_HIT_SHADOW 1 (default): a ShadowMap ray only reports whether its closest hit casts a shadow, so a ray
+ *                          that stays clear of the box round the scene's non-casting triangles (it can only meet casters)
+ *                          ends its walk at the first hit it accepts.  Same shadow map bit for bit.
  *   RT_OPT_OVERLAP_SHADOW  1 (default): in rt_render_frames, when the ShadowMap pass shares CSMain's primary hits, its rays
  *                          are walked WHILE the later bounces run: one launch on a stream masked to all compute units but
  *                          a few, the remaining bounce and shading launches on a stream masked to those few, a last launch
@@ -398,6 +401,7 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
 #define RT_OPT_OVERLAP_SHADOW 6
 #define RT_OPT_OVERLAP_AFTER 7
 #define RT_OPT_OVERLAP_CUS 8
+#define RT_OPT_FIRST_HIT_SHADOW 9
 int rt_set_option(RtContext *ctx, int option, int value);
 
 /* ------------------------------------------------------------------- stats */

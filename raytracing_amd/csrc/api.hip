@@ -174,6 +174,21 @@ int rt_scene_upload(RtContext *ctx, const RtMeshVertex *vertices, uint32_t n_ver
     if (n_triangles >= 0x7FFFFFFFu) return rt_fail(ctx, RT_E_INVALID, "too many triangles");
     for (uint32_t i = 0; i < n_indices; ++i)   // every index a kernel dereferences is checked here
         if (indices[i] >= n_vertices) return rt_fail(ctx, RT_E_INVALID, "index %u out of range at %u", indices[i], i);
+    // box round the triangles that cast no shadow (MeshData.compute:127 reads the flag from [0]); min > max: none
+    RtAABB nc;
+    for (int a = 0; a < 3; ++a) nc.min[a] = rt_inf(), nc.max[a] = -rt_inf();
+    nc._dummy0 = nc._dummy1 = 0.0f;
+    for (uint32_t t = 0; t < n_triangles; ++t) {
+        if (shadow_index_xy[2 * (size_t)t] > 0) continue;
+        for (int k = 0; k < 3; ++k) {
+            const float *p = vertices[indices[3 * (size_t)t + k]].position;
+            for (int a = 0; a < 3; ++a) {
+                if (!(p[a] >= nc.min[a])) nc.min[a] = p[a] == p[a] ? p[a] : -rt_inf();      // a NaN coordinate opens the box
+                if (!(p[a] <= nc.max[a])) nc.max[a] = p[a] == p[a] ? p[a] : rt_inf();
+            }
+        }
+    }
+    ctx->nonCasterBox = nc;
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int rc;
     if ((rc = upload(ctx, &ctx->dVerts, vertices, n_vertices))) return rc;
@@ -532,6 +547,7 @@ int rt_set_option(RtContext *ctx, int option, int value)
     case RT_OPT_PACKET_TRACE: ctx->optPacketTrace = value != 0; return RT_OK;
     case RT_OPT_MATERIAL_SORT: ctx->optMaterialSort = value != 0; return RT_OK;
     case RT_OPT_TWO_STREAMS: ctx->optTwoStreams = value != 0; return RT_OK;
+    case RT_OPT_FIRST_HIT_SHADOW: ctx->optFirstHitShadow = value != 0; return RT_OK;
     case RT_OPT_OVERLAP_SHADOW: ctx->optOverlapShadow = value != 0; return RT_OK;
     case RT_OPT_OVERLAP_AFTER:
         if (value < 0 || value > 6) return rt_fail(ctx, RT_E_INVALID, "RT_OPT_OVERLAP_AFTER must be 0..6");

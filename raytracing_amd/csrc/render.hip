@@ -58,6 +58,8 @@ __device__ __forceinline__ void block_queue_flush(const uint32_t *stage, uint32_
 
 // ------------------------------------------------------------------ ray sources for traverse_rays
 struct ArraySrc {            // caller rays (rt_trace_rays)
+    static constexpr bool FIRST_HIT_MAY_DECIDE = false;
+    __device__ __forceinline__ bool first_hit_decides(const rt_f3, const rt_f3) const { return false; }
     const float4 *org, *dir;
     uint32_t n;
     RtHitRec *hits;
@@ -72,6 +74,8 @@ struct ArraySrc {            // caller rays (rt_trace_rays)
 };
 
 struct QueueSrc {            // live paths of one bounce
+    static constexpr bool FIRST_HIT_MAY_DECIDE = false;
+    __device__ __forceinline__ bool first_hit_decides(const rt_f3, const rt_f3) const { return false; }
     const uint32_t *queue, *qcount;
     const float4 *po, *pd;
     RtHitRec *hit;
@@ -101,6 +105,18 @@ struct ShadowSrc {
     const RtLeafShade *leafShade;
     rt_f3 lightDir, lightTangent, lightBitangent;
     float lightRadius;
+    // All a shadow ray reports is whether its closest hit casts a shadow.  A ray that stays clear of the
+    // box round the triangles that do NOT cast one (ncMin > ncMax: there are none) can only meet casters,
+    // so its first accepted hit settles the answer and the walk ends there.  The box is tested the way the
+    // reference tests a triangle's own box before the triangle, and that test is monotone in the box: a ray
+    // that passes the box of such a triangle passes this one.
+    static constexpr bool FIRST_HIT_MAY_DECIDE = true;
+    float ncMin[3], ncMax[3];
+    __device__ __forceinline__ bool first_hit_decides(const rt_f3 o, const rt_f3 d) const
+    {
+        if (ncMin[0] > ncMax[0]) return true;
+        return !box_hit_exact(ncMin[0], ncMin[1], ncMin[2], ncMax[0], ncMax[1], ncMax[2], o, d);
+    }
     __device__ __forceinline__ uint32_t count() const { return *smqCount * 16u; }
     __device__ __forceinline__ void load(uint32_t i, rt_f3 &o, rt_f3 &d) const
     {
@@ -738,6 +754,10 @@ static ShadowSrc shadow_source(RtContext *ctx)
     sh.lightTangent = rt_normalize3(rt_cross3(sh.lightDir, rt_mk3(0.0f, 1.0f, 0.0f)));
     sh.lightBitangent = rt_normalize3(rt_cross3(sh.lightTangent, sh.lightDir));
     sh.lightRadius = P.lightParameter[3];
+    for (int a = 0; a < 3; ++a) {
+        sh.ncMin[a] = ctx->optFirstHitShadow ? ctx->nonCasterBox.min[a] : -rt_inf();
+        sh.ncMax[a] = ctx->optFirstHitShadow ? ctx->nonCasterBox.max[a] : rt_inf();
+    }
     return sh;
 }
 

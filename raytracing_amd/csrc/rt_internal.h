@@ -205,6 +205,8 @@ struct RtContext {
     float *dSeeds = nullptr;              // per-frame seeds of the batch in flight
     bool optPacketShadow = false, optPacketPrimary = false, optPacketTrace = false;
     bool optMaterialSort = true, optTwoStreams = false;
+    RtAABB nonCasterBox = {{0, 0, 0}, 0, {0, 0, 0}, 0};   // round the triangles whose castShadow flag is not set (rt_scene_upload)
+    bool optFirstHitShadow = true;        // shadow rays that cannot meet a non-casting triangle stop at their first hit
     bool optOverlapShadow = true;         // walk the shadow rays while the later bounces run (render.hip, overlap_fork)
     uint32_t optOverlapAfter = 1;         // ... from the extend launch of this bounce on
     uint32_t optOverlapCUs = 32;          // compute units the bounce launches keep meanwhile

@@ -291,6 +291,38 @@ def test_shadow_rays_walked_while_the_bounces_run_do_not_change_a_bit(core):
         H.assert_bits_equal(images[0][1], images[k][1], f"shadow map, overlap variant {k}")
 
 
+@pytest.mark.parametrize("non_casters", ["ground only", "a third of the car", "none", "all"])
+def test_shadow_rays_that_stop_at_their_first_hit_do_not_change_a_bit(core, non_casters):
+    """A ShadowMap ray that stays clear of the box round the non-casting triangles ends at its first accepted hit;
+    the shadow map is the one of the full closest-hit walk, wherever the non-casters are."""
+    import copy
+    sc = copy.copy(scenes.car_standin(96, 64, detail=0.02))
+    sh = np.array(sc.shadow_index, np.int32, copy=True)
+    if non_casters == "a third of the car":
+        sh[2::3, 0] = 0
+    elif non_casters == "none":
+        sh[:, 0] = 1
+    elif non_casters == "all":
+        sh[:, 0] = 0
+    sc.shadow_index = sh
+    seeds = scenes.frame_seeds(4, seed=13)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(sc.params)
+    images = []
+    for on in (0, 1):
+        core.set_option(wire.OPT_FIRST_HIT_SHADOW, on)
+        core.set_dirty()
+        core.render_frames(seeds)
+        images.append((core.readback(wire.IMAGE_CONVERGED), core.readback(wire.IMAGE_SHADOWMAP)))
+    H.assert_bits_equal(images[0][0], images[1][0], "converged image, first-hit shortcut off vs on")
+    H.assert_bits_equal(images[0][1], images[1][1], "shadow map, first-hit shortcut off vs on")
+    if non_casters in ("ground only", "none"):
+        assert (images[0][1][..., 0] < 1).any()
+    if non_casters == "all":
+        assert (images[0][1][..., :3] == 1).all()
+
+
 def test_tiles_union_is_bit_identical_to_whole_frame(core):
     sc = scenes.cornell_box(200, 136, sphere_segments=16)     # not a multiple of the tile size
     seeds = scenes.frame_seeds(2, seed=6)
