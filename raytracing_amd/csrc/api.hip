@@ -126,6 +126,7 @@ int rt_create(int device_id, RtContext **out_ctx)
         hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void **)&ctx->dStats, 64 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMalloc((void **)&ctx->dNonCasters, RT_NONCASTER_LIST * 64) != hipSuccess ||
         hipMalloc((void **)&ctx->dErrorFlag, 4) != hipSuccess || hipMalloc((void **)&ctx->dQCount, RT_COUNTER_BLOCK_WORDS * 4) != hipSuccess ||
         hipMalloc((void **)&ctx->dStackSpill, (size_t)RT_SPILL_AREAS * ctx->numCU * RT_SPILL_WORDS_PER_CU * 4) != hipSuccess) {
         delete ctx;
@@ -150,7 +151,7 @@ int rt_destroy(RtContext *ctx)
     rt_free_post(ctx);
     rt_free_brute(ctx);
     void *ptrs[] = {ctx->dVerts, ctx->dIdx, ctx->dMatIdx, ctx->dShadow, ctx->dMats, ctx->dSphere, ctx->dArea,
-                    ctx->dDisc, ctx->dCube, ctx->dStats, ctx->dErrorFlag, ctx->dQCount, ctx->dStackSpill};
+                    ctx->dDisc, ctx->dCube, ctx->dStats, ctx->dErrorFlag, ctx->dQCount, ctx->dStackSpill, ctx->dNonCasters};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2), (void)hipStreamDestroy(ctx->stream2);
@@ -174,22 +175,37 @@ int rt_scene_upload(RtContext *ctx, const RtMeshVertex *vertices, uint32_t n_ver
     if (n_triangles >= 0x7FFFFFFFu) return rt_fail(ctx, RT_E_INVALID, "too many triangles");
     for (uint32_t i = 0; i < n_indices; ++i)   // every index a kernel dereferences is checked here
         if (indices[i] >= n_vertices) return rt_fail(ctx, RT_E_INVALID, "index %u out of range at %u", indices[i], i);
-    // box round the triangles that cast no shadow (MeshData.compute:127 reads the flag from [0]); min > max: none
+    // Box round the OWN BOXES (as the build makes them, k_calculate: vertex extremes -+ 0.001, the same float
+    // operations) of the triangles that cast no shadow (MeshData.compute:127 reads the flag from [0]); min > max: none.
+    // While they are few, their records as well, in the layout and with the float operations of k_pack_leaves.
     RtAABB nc;
     for (int a = 0; a < 3; ++a) nc.min[a] = rt_inf(), nc.max[a] = -rt_inf();
     nc._dummy0 = nc._dummy1 = 0.0f;
+    float records[RT_NONCASTER_LIST][16];
+    uint32_t nNc = 0;
     for (uint32_t t = 0; t < n_triangles; ++t) {
         if (shadow_index_xy[2 * (size_t)t] > 0) continue;
-        for (int k = 0; k < 3; ++k) {
-            const float *p = vertices[indices[3 * (size_t)t + k]].position;
-            for (int a = 0; a < 3; ++a) {
-                if (!(p[a] >= nc.min[a])) nc.min[a] = p[a] == p[a] ? p[a] : -rt_inf();      // a NaN coordinate opens the box
-                if (!(p[a] <= nc.max[a])) nc.max[a] = p[a] == p[a] ? p[a] : rt_inf();
-            }
+        const float *p0 = vertices[indices[3 * (size_t)t]].position, *p1 = vertices[indices[3 * (size_t)t + 1]].position,
+                    *p2 = vertices[indices[3 * (size_t)t + 2]].position;
+        float mn[3], mx[3];
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = rt_min(rt_min(p0[a], p1[a]), p2[a]) - 0.001f;
+            mx[a] = rt_max(rt_max(p0[a], p1[a]), p2[a]) + 0.001f;
+            if (!(mn[a] >= nc.min[a])) nc.min[a] = mn[a] == mn[a] ? mn[a] : -rt_inf();      // a NaN coordinate opens the box
+            if (!(mx[a] <= nc.max[a])) nc.max[a] = mx[a] == mx[a] ? mx[a] : rt_inf();
         }
+        if (nNc < RT_NONCASTER_LIST) {
+            const float rec[16] = {p0[0], p0[1], p0[2], p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], p2[0] - p0[0], p2[1] - p0[1],
+                                   p2[2] - p0[2], 0.0f, mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]};
+            memcpy(records[nNc], rec, sizeof rec);
+        }
+        nNc += 1;
     }
-    ctx->nonCasterBox = nc;
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->nNonCasters = nNc;
+    if (nNc && nNc <= RT_NONCASTER_LIST)
+        RT_HIP(ctx, hipMemcpy(ctx->dNonCasters, records, (size_t)nNc * 64, hipMemcpyHostToDevice));
+    ctx->nonCasterBox = nc;
     int rc;
     if ((rc = upload(ctx, &ctx->dVerts, vertices, n_vertices))) return rc;
     if ((rc = upload(ctx, &ctx->dIdx, indices, n_indices))) return rc;

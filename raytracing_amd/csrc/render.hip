@@ -59,7 +59,7 @@ __device__ __forceinline__ void block_queue_flush(const uint32_t *stage, uint32_
 // ------------------------------------------------------------------ ray sources for traverse_rays
 struct ArraySrc {            // caller rays (rt_trace_rays)
     static constexpr bool FIRST_HIT_MAY_DECIDE = false;
-    __device__ __forceinline__ bool first_hit_decides(const rt_f3, const rt_f3) const { return false; }
+    __device__ __forceinline__ bool first_hit_decides(const rt_f3, const rt_f3, const rt_f3) const { return false; }
     const float4 *org, *dir;
     uint32_t n;
     RtHitRec *hits;
@@ -75,7 +75,7 @@ struct ArraySrc {            // caller rays (rt_trace_rays)
 
 struct QueueSrc {            // live paths of one bounce
     static constexpr bool FIRST_HIT_MAY_DECIDE = false;
-    __device__ __forceinline__ bool first_hit_decides(const rt_f3, const rt_f3) const { return false; }
+    __device__ __forceinline__ bool first_hit_decides(const rt_f3, const rt_f3, const rt_f3) const { return false; }
     const uint32_t *queue, *qcount;
     const float4 *po, *pd;
     RtHitRec *hit;
@@ -105,17 +105,31 @@ struct ShadowSrc {
     const RtLeafShade *leafShade;
     rt_f3 lightDir, lightTangent, lightBitangent;
     float lightRadius;
-    // All a shadow ray reports is whether its closest hit casts a shadow.  A ray that stays clear of the
-    // box round the triangles that do NOT cast one (ncMin > ncMax: there are none) can only meet casters,
-    // so its first accepted hit settles the answer and the walk ends there.  The box is tested the way the
-    // reference tests a triangle's own box before the triangle, and that test is monotone in the box: a ray
-    // that passes the box of such a triangle passes this one.
+    // All a shadow ray reports is whether its closest hit casts a shadow.  A ray that no NON-casting triangle
+    // can accept only meets casters, so its first accepted hit settles the answer and the walk ends there.
+    // Asked once per ray, when it first holds a hit: the ray is tested against the box round the own boxes
+    // of the non-casting triangles (ncMin > ncMax: there are none) the way the reference tests a triangle's own
+    // box before the triangle -- that test is monotone in the box, a ray that passes the box of such a
+    // triangle passes this one -- and, where it passes and the non-casters are few (a ground quad), against
+    // each of them with the acceptance test itself.
     static constexpr bool FIRST_HIT_MAY_DECIDE = true;
     float ncMin[3], ncMax[3];
-    __device__ __forceinline__ bool first_hit_decides(const rt_f3 o, const rt_f3 d) const
+    const float4 *ncTri;       // records of the non-casters, leafTri layout
+    uint32_t nNc;              // how many; above RT_NONCASTER_LIST the box alone decides
+    __device__ __forceinline__ bool first_hit_decides(const rt_f3 o, const rt_f3 d, const rt_f3 r) const
     {
         if (ncMin[0] > ncMax[0]) return true;
-        return !box_hit_exact(ncMin[0], ncMin[1], ncMin[2], ncMax[0], ncMax[1], ncMax[2], o, d);
+        if (!box_hit(ncMin[0], ncMin[1], ncMin[2], ncMax[0], ncMax[1], ncMax[2], o, d, r)) return true;
+        if (nNc > RT_NONCASTER_LIST) return false;
+        for (uint32_t k = 0; k < nNc; ++k) {
+            const float4 a = ncTri[k * 4], b = ncTri[k * 4 + 1], c = ncTri[k * 4 + 2], e = ncTri[k * 4 + 3];
+            RtHitRec cand;
+            cand.t = rt_inf(); cand.u = 0.0f; cand.v = 0.0f; cand.leaf = RT_INVALID;
+            if (tri_test_values(rt_mk3(a.x, a.y, a.z), rt_mk3(a.w, b.x, b.y), rt_mk3(b.z, b.w, c.x), 0u, o, d, cand) &&
+                box_hit(c.z, c.w, e.x, e.y, e.z, e.w, o, d, r))
+                return false;
+        }
+        return true;
     }
     __device__ __forceinline__ uint32_t count() const { return *smqCount * 16u; }
     __device__ __forceinline__ void load(uint32_t i, rt_f3 &o, rt_f3 &d) const
@@ -754,6 +768,8 @@ static ShadowSrc shadow_source(RtContext *ctx)
     sh.lightTangent = rt_normalize3(rt_cross3(sh.lightDir, rt_mk3(0.0f, 1.0f, 0.0f)));
     sh.lightBitangent = rt_normalize3(rt_cross3(sh.lightTangent, sh.lightDir));
     sh.lightRadius = P.lightParameter[3];
+    sh.ncTri = ctx->dNonCasters;
+    sh.nNc = ctx->nNonCasters;
     for (int a = 0; a < 3; ++a) {
         sh.ncMin[a] = ctx->optFirstHitShadow ? ctx->nonCasterBox.min[a] : -rt_inf();
         sh.ncMax[a] = ctx->optFirstHitShadow ? ctx->nonCasterBox.max[a] : rt_inf();

@@ -136,6 +136,7 @@ struct RtPendingEvent {
 
 #define RT_COUNTER_BLOCK_WORDS 1536 // queue counts and ray cursors (dQCount), a 128-byte line each, one set per stream
 #define RT_SPILL_WORDS_PER_CU (2048 * RT_STACK_DEPTH)   // room for every stack level of 2048 lanes per CU
+#define RT_NONCASTER_LIST 8                             // non-casting triangles a shadow ray is tested against one by one
 #define RT_SPILL_AREAS 2                                // walker launches that may be on the chip together
 
 struct RtPostState;   // post.hip
@@ -205,6 +206,8 @@ struct RtContext {
     float *dSeeds = nullptr;              // per-frame seeds of the batch in flight
     bool optPacketShadow = false, optPacketPrimary = false, optPacketTrace = false;
     bool optMaterialSort = true, optTwoStreams = false;
+    float4 *dNonCasters = nullptr;        // leafTri-layout records of the non-casting triangles while they are at most RT_NONCASTER_LIST
+    uint32_t nNonCasters = 0;
     RtAABB nonCasterBox = {{0, 0, 0}, 0, {0, 0, 0}, 0};   // round the triangles whose castShadow flag is not set (rt_scene_upload)
     bool optFirstHitShadow = true;        // shadow rays that cannot meet a non-casting triangle stop at their first hit
     bool optOverlapShadow = true;         // walk the shadow rays while the later bounces run (render.hip, overlap_fork)

@@ -247,7 +247,8 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
     RayFeed feed;
     feed.init(cursor, src.count());
 
-    bool hasRay = false, odd = false, popped = false, firstHitDecides = false;
+    bool hasRay = false, odd = false, popped = false;
+    uint32_t firstHit = 0;      // does this ray's first hit settle its answer: 0 not asked yet, 1 yes, 2 no
     uint32_t rayIdx = 0, node = TRV_DONE, sp = 0, npend = 0, tos = TRV_DONE, below = TRV_DONE;
     rt_f3 o = rt_splat3(0.0f), d = rt_splat3(0.0f), r = rt_splat3(0.0f);
     RtRaySlab slab;
@@ -275,7 +276,7 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                 src.load(mine, o, d);
                 r = rt_mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                 odd = rt_ray_needs_exact_walk(o, d);
-                if (Src::FIRST_HIT_MAY_DECIDE) firstHitDecides = !odd && src.first_hit_decides(o, d);
+                firstHit = 0;
                 slab = rt_ray_slab(sv.grid, o, r);
                 h.t = rt_inf(); h.u = 0.0f; h.v = 0.0f; h.leaf = RT_INVALID;
                 hasRay = true;
@@ -444,7 +445,10 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
             }
         }
         npend = 0;
-        if (Src::FIRST_HIT_MAY_DECIDE && firstHitDecides && h.leaf != RT_INVALID) node = TRV_DONE;    // retired below
+        if (Src::FIRST_HIT_MAY_DECIDE && hasRay && h.leaf != RT_INVALID && node != TRV_DONE && firstHit != 2u) {
+            if (firstHit == 0u) firstHit = (!odd && src.first_hit_decides(o, d, r)) ? 1u : 2u;
+            if (firstHit == 1u) node = TRV_DONE;               // retired below
+        }
         TRV_PHASE(2)
 
         // ---- retire finished rays

@@ -291,13 +291,29 @@ def test_shadow_rays_walked_while_the_bounces_run_do_not_change_a_bit(core):
         H.assert_bits_equal(images[0][1], images[k][1], f"shadow map, overlap variant {k}")
 
 
-@pytest.mark.parametrize("non_casters", ["ground only", "a third of the car", "none", "all"])
+@pytest.mark.parametrize("non_casters", ["ground only", "a third of the car", "none", "all", "a flat sheet under the car"])
 def test_shadow_rays_that_stop_at_their_first_hit_do_not_change_a_bit(core, non_casters):
     """A ShadowMap ray that stays clear of the box round the non-casting triangles ends at its first accepted hit;
     the shadow map is the one of the full closest-hit walk, wherever the non-casters are."""
     import copy
     sc = copy.copy(scenes.car_standin(96, 64, detail=0.02))
+    if non_casters == "a flat sheet under the car":
+        # an axis-parallel non-casting quad between the ground and the car, facing down: the shadow rays of the
+        # ground under the car meet it before any caster, and its own box is flat but for the build's padding
+        extra = scenes.SceneBuilder()
+        s = 0.7071068
+        extra.add(scenes.quad_mesh(), scenes.material_data((0.2, 0.8, 0.2, 1), 0, 0.5), (0, 0.04, 0), (-s, 0, 0, s), (1.2, 0.6, 1),
+                  cast_shadow=False)
+        e = extra.build("sheet")
+        nv = len(sc.vertices)
+        sc.vertices = np.concatenate([sc.vertices, e.vertices])
+        sc.indices = np.concatenate([sc.indices, e.indices + nv]).astype(np.uint32)
+        sc.material_index = np.concatenate([sc.material_index, e.material_index + len(sc.materials)]).astype(np.uint32)
+        sc.shadow_index = np.concatenate([sc.shadow_index, e.shadow_index]).astype(np.int32)
+        sc.materials = np.concatenate([sc.materials, e.materials])
     sh = np.array(sc.shadow_index, np.int32, copy=True)
+    if non_casters == "a flat sheet under the car":
+        sh[:-2, 0] = 1                # the sheet alone: the box round the non-casters is as flat as it
     if non_casters == "a third of the car":
         sh[2::3, 0] = 0
     elif non_casters == "none":
@@ -317,7 +333,7 @@ def test_shadow_rays_that_stop_at_their_first_hit_do_not_change_a_bit(core, non_
         images.append((core.readback(wire.IMAGE_CONVERGED), core.readback(wire.IMAGE_SHADOWMAP)))
     H.assert_bits_equal(images[0][0], images[1][0], "converged image, first-hit shortcut off vs on")
     H.assert_bits_equal(images[0][1], images[1][1], "shadow map, first-hit shortcut off vs on")
-    if non_casters in ("ground only", "none"):
+    if non_casters in ("ground only", "none", "a flat sheet under the car"):
         assert (images[0][1][..., 0] < 1).any()
     if non_casters == "all":
         assert (images[0][1][..., :3] == 1).all()
