@@ -28,6 +28,7 @@
 #include "../include/rt_math.h"
 #include "../include/rt_q16.h"
 #include "../include/rt_finekey.h"
+#include "../include/rt_rotate.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -356,6 +357,8 @@ void BVHConstructor(Scene &s)
     }
 }
 
+void RotateWalkTree(Scene &w);
+
 // The library's traversal boxes: every child box of the tree rounded outward onto
 // the 16-bit grid of the root box (include/rt_q16.h), 3 words per box.
 // The tree the library's rays walk (no reference counterpart): the reference's own steps on finer keys.
@@ -380,6 +383,90 @@ void BuildWalkTree(Scene &s)
     w.morton = keys;
     TreeConstructor(w);
     BVHConstructor(w);
+    for (int pass = 0; pass < RT_ROTATION_PASSES; ++pass) RotateWalkTree(w);
+}
+
+// Tree rotations on the walk tree (no reference counterpart; include/rt_rotate.h): one bottom-up pass, every
+// node after its children.
+void RotateWalkTree(Scene &w)
+{
+    const uint32_t N = w.N;
+    if (N < 3) return;
+    auto boxOf = [&](uint32_t node, uint32_t type, float out[6]) {
+        const RtAABB &b = type == RT_INTERNAL_NODE ? w.bvhData[node] : w.triAABB[w.sortedIdx[w.leaves[node].index]];
+        for (int k = 0; k < 3; ++k) out[k] = b.min[k], out[3 + k] = b.max[k];
+    };
+    auto setParent = [&](uint32_t node, uint32_t type, uint32_t parent) {
+        if (type == RT_INTERNAL_NODE) w.inodes[node].parent = parent;
+        else w.leaves[node].parent = parent;
+    };
+    auto refit = [&](uint32_t node) {
+        const RtInternalNode &n = w.inodes[node];
+        float a[6], b[6], m[6];
+        boxOf(n.leftNode, n.leftNodeType, a);
+        boxOf(n.rightNode, n.rightNodeType, b);
+        rt_box_merge(a, b, m);
+        RtAABB &o = w.bvhData[node];
+        for (int k = 0; k < 3; ++k) o.min[k] = m[k], o.max[k] = m[3 + k];
+    };
+    std::vector<uint32_t> order;
+    order.reserve(N - 1);
+    std::vector<uint32_t> stack{0};
+    while (!stack.empty()) {
+        const uint32_t i = stack.back();
+        stack.pop_back();
+        order.push_back(i);
+        const RtInternalNode &n = w.inodes[i];
+        if (n.leftNodeType == RT_INTERNAL_NODE) stack.push_back(n.leftNode);
+        if (n.rightNodeType == RT_INTERNAL_NODE) stack.push_back(n.rightNode);
+    }
+    for (size_t k = order.size(); k-- > 0;) {      // reversed pre-order: children before parents
+        const uint32_t x = order[k];
+        RtInternalNode &X = w.inodes[x];
+        const bool lInt = X.leftNodeType == RT_INTERNAL_NODE, rInt = X.rightNodeType == RT_INTERNAL_NODE;
+        float L[6], R[6], La[6] = {0}, Lb[6] = {0}, Ra[6] = {0}, Rb[6] = {0};
+        boxOf(X.leftNode, X.leftNodeType, L);
+        boxOf(X.rightNode, X.rightNodeType, R);
+        if (lInt) {
+            const RtInternalNode &c = w.inodes[X.leftNode];
+            boxOf(c.leftNode, c.leftNodeType, La);
+            boxOf(c.rightNode, c.rightNodeType, Lb);
+        }
+        if (rInt) {
+            const RtInternalNode &c = w.inodes[X.rightNode];
+            boxOf(c.leftNode, c.leftNodeType, Ra);
+            boxOf(c.rightNode, c.rightNodeType, Rb);
+        }
+        const int which = rt_pick_rotation(lInt, rInt, L, R, La, Lb, Ra, Rb);
+        if (which == 1 || which == 2) {
+            const uint32_t r = X.rightNode;
+            RtInternalNode &C = w.inodes[r];
+            uint32_t &gn = which == 1 ? C.leftNode : C.rightNode, &gt = which == 1 ? C.leftNodeType : C.rightNodeType;
+            std::swap(X.leftNode, gn);
+            std::swap(X.leftNodeType, gt);
+            setParent(X.leftNode, X.leftNodeType, x);
+            setParent(gn, gt, r);
+            refit(r);
+        } else if (which == 5 || which == 6) {
+            RtInternalNode &A = w.inodes[X.leftNode], &B = w.inodes[X.rightNode];
+            uint32_t &gn = which == 5 ? B.leftNode : B.rightNode, &gt = which == 5 ? B.leftNodeType : B.rightNodeType;
+            std::swap(A.leftNode, gn);
+            std::swap(A.leftNodeType, gt);
+            setParent(A.leftNode, A.leftNodeType, X.leftNode);
+            setParent(gn, gt, X.rightNode);
+            refit(X.leftNode);
+            refit(X.rightNode);
+        } else if (which == 3 || which == 4) {
+            const uint32_t l = X.leftNode;
+            RtInternalNode &C = w.inodes[l];
+            uint32_t &gn = which == 3 ? C.leftNode : C.rightNode, &gt = which == 3 ? C.leftNodeType : C.rightNodeType;
+            std::swap(X.rightNode, gn);
+            std::swap(X.rightNodeType, gt);
+            setParent(X.rightNode, X.rightNodeType, x);
+            setParent(gn, gt, l);
+            refit(l);
+        }
+    }
 }
 
 // Order in which IntersectTriangle (BVHRayTracing.cginc:78-123) meets the triangles when every box passes.

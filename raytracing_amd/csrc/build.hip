@@ -11,6 +11,7 @@
 //   Assets/Shaders/BVH/BVH.compute:164-211               (k_fit, level-synchronous, no atomics)
 #include "rt_internal.h"
 #include "../../include/rt_finekey.h"
+#include "../../include/rt_rotate.h"
 
 #define WAVE 64
 #define SORT_THREADS 256
@@ -361,6 +362,104 @@ __global__ __launch_bounds__(256) void k_fit(uint32_t N, uint32_t iter, const ui
     done[i] = iter;
 }
 
+// ------------------------------------------------------------------ tree rotations (traversal tree only)
+// One bottom-up pass of include/rt_rotate.h, level by level like k_fit: node i is handled in launch `iter`
+// when its internal children were handled in an earlier launch.  A swap rewrites the links of i and of
+// the child that changes and that child's box; nobody else reads those before a later launch (the child
+// is finished, i's parent waits for i).  Parent pointers are not kept up (nothing reads them afterwards).
+__device__ __forceinline__ void load_box(uint32_t child, const uint32_t *__restrict__ sortedIdx, const float4 *__restrict__ triAABB,
+                                         const float4 *bvhData, float out[6])
+{
+    float4 mn, mx;
+    if (child & RT_LEAF_BIT) {
+        const uint32_t t = sortedIdx[child & ~RT_LEAF_BIT];
+        mn = triAABB[t * 2];
+        mx = triAABB[t * 2 + 1];
+    } else {
+        mn = bvhData[child * 2];
+        mx = bvhData[child * 2 + 1];
+    }
+    out[0] = mn.x; out[1] = mn.y; out[2] = mn.z; out[3] = mx.x; out[4] = mx.y; out[5] = mx.z;
+}
+
+__global__ __launch_bounds__(256) void k_rotate(uint32_t N, uint32_t iter, uint32_t *left, uint32_t *right,
+                                                 const uint32_t *__restrict__ sortedIdx, const float4 *__restrict__ triAABB,
+                                                 float4 *bvhData, uint32_t *done)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N - 1) return;
+    if (done[i] != FIT_UNDONE) return;
+    const uint32_t l = left[i], r = right[i];
+    const bool lInt = !(l & RT_LEAF_BIT), rInt = !(r & RT_LEAF_BIT);
+    if (lInt && done[l] >= iter) return;
+    if (rInt && done[r] >= iter) return;
+    float L[6], R[6], La[6] = {0, 0, 0, 0, 0, 0}, Lb[6] = {0, 0, 0, 0, 0, 0}, Ra[6] = {0, 0, 0, 0, 0, 0}, Rb[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t la = 0, lb = 0, ra = 0, rb = 0;
+    load_box(l, sortedIdx, triAABB, bvhData, L);
+    load_box(r, sortedIdx, triAABB, bvhData, R);
+    if (lInt) {
+        la = left[l]; lb = right[l];
+        load_box(la, sortedIdx, triAABB, bvhData, La);
+        load_box(lb, sortedIdx, triAABB, bvhData, Lb);
+    }
+    if (rInt) {
+        ra = left[r]; rb = right[r];
+        load_box(ra, sortedIdx, triAABB, bvhData, Ra);
+        load_box(rb, sortedIdx, triAABB, bvhData, Rb);
+    }
+    const int which = rt_pick_rotation(lInt, rInt, L, R, La, Lb, Ra, Rb);
+    float m[6];
+    if (which == 1) {            // L <-> R.left: R = (L, Rb)
+        left[i] = ra; left[r] = l;
+        rt_box_merge(L, Rb, m);
+    } else if (which == 2) {     // L <-> R.right: R = (Ra, L)
+        left[i] = rb; right[r] = l;
+        rt_box_merge(Ra, L, m);
+    } else if (which == 3) {     // R <-> L.left: L = (R, Lb)
+        right[i] = la; left[l] = r;
+        rt_box_merge(R, Lb, m);
+    } else if (which == 4) {     // R <-> L.right: L = (La, R)
+        right[i] = lb; right[l] = r;
+        rt_box_merge(La, R, m);
+    }
+    if (which >= 1 && which <= 4) {
+        const uint32_t c = which <= 2 ? r : l;
+        bvhData[c * 2 + 0] = make_float4(m[0], m[1], m[2], 0.0f);
+        bvhData[c * 2 + 1] = make_float4(m[3], m[4], m[5], 0.0f);
+    } else if (which >= 5) {     // 5: La <-> Ra, 6: La <-> Rb: both children change
+        float n[6];
+        if (which == 5) {
+            left[l] = ra; left[r] = la;
+            rt_box_merge(Ra, Lb, m); rt_box_merge(La, Rb, n);
+        } else {
+            left[l] = rb; right[r] = la;
+            rt_box_merge(Rb, Lb, m); rt_box_merge(Ra, La, n);
+        }
+        bvhData[l * 2 + 0] = make_float4(m[0], m[1], m[2], 0.0f);
+        bvhData[l * 2 + 1] = make_float4(m[3], m[4], m[5], 0.0f);
+        bvhData[r * 2 + 0] = make_float4(n[0], n[1], n[2], 0.0f);
+        bvhData[r * 2 + 1] = make_float4(n[3], n[4], n[5], 0.0f);
+    }
+    done[i] = iter;
+}
+
+// The exact 64-byte nodes (both child boxes + links) of a tree whose links and boxes are final.
+__global__ __launch_bounds__(256) void k_emit_nodes(uint32_t N, const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
+                                                     const uint32_t *__restrict__ sortedIdx, const float4 *__restrict__ triAABB,
+                                                     const float4 *__restrict__ bvhData, float4 *__restrict__ nodes)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N - 1) return;
+    const uint32_t l = left[i], r = right[i];
+    float a[6], b[6];
+    load_box(l, sortedIdx, triAABB, bvhData, a);
+    load_box(r, sortedIdx, triAABB, bvhData, b);
+    nodes[i * 4 + 0] = make_float4(a[0], a[1], a[2], a[3]);
+    nodes[i * 4 + 1] = make_float4(a[4], a[5], b[0], b[1]);
+    nodes[i * 4 + 2] = make_float4(b[2], b[3], b[4], b[5]);
+    nodes[i * 4 + 3] = make_float4(__uint_as_float(l), __uint_as_float(r), 0.0f, 0.0f);
+}
+
 // ------------------------------------------------------------------ 16-bit traversal nodes
 // Rounds every child box of the finished tree outward onto the root-box grid
 // (rt_q16.h).  A plane the grid cannot cover raises the error flag.
@@ -690,6 +789,30 @@ int rt_build_impl(RtContext *ctx)
         rt_timer_end(ctx);
         if ((rc = build_tree_from_keys(ctx, sc, N, wKeys, wSortedIdx, wCodes, wLeft, wRight, wParent, wLeafParent, nullptr, wBvhData, wNodes)))
             return rc;
+        if (N >= 3) {
+            for (int pass = 0; pass < RT_ROTATION_PASSES; ++pass) {
+                RT_HIP(ctx, hipMemsetAsync(sc.done, 0xFF, (size_t)NI * 4, st));
+                uint32_t rootDone = FIT_UNDONE;
+                // a rotation can lengthen a path by one level, so the height is no longer bounded by the key width
+                for (uint32_t iter = 0; iter < 4096 && rootDone == FIT_UNDONE; ++iter) {
+                    rt_timer_begin(ctx, "k_rotate");
+                    hipLaunchKernelGGL(k_rotate, gridNI, blk, 0, st, N, iter, wLeft, wRight, wSortedIdx, (const float4 *)ctx->dTriAABB,
+                                       (float4 *)wBvhData, sc.done);
+                    rt_timer_end(ctx);
+                    if ((iter & 7u) == 7u) {
+                        RT_HIP(ctx, hipMemcpyAsync(&rootDone, sc.done, 4, hipMemcpyDeviceToHost, st));
+                        RT_HIP(ctx, hipStreamSynchronize(st));
+                    }
+                }
+                RT_HIP(ctx, hipMemcpyAsync(&rootDone, sc.done, 4, hipMemcpyDeviceToHost, st));
+                RT_HIP(ctx, hipStreamSynchronize(st));
+                if (rootDone == FIT_UNDONE) return rt_fail(ctx, RT_E_STATE, "tree rotation pass did not reach the root");
+            }
+            rt_timer_begin(ctx, "k_emit_nodes");
+            hipLaunchKernelGGL(k_emit_nodes, gridNI, blk, 0, st, N, wLeft, wRight, wSortedIdx, (const float4 *)ctx->dTriAABB,
+                               (const float4 *)wBvhData, (float4 *)wNodes);
+            rt_timer_end(ctx);
+        }
         rt_timer_begin(ctx, "k_quantise");
         hipLaunchKernelGGL(k_quantise, gridNI, blk, 0, st, NI, ctx->grid, wNodes, (uint4 *)ctx->dQNodes, ctx->dErrorFlag);
         rt_timer_end(ctx);

@@ -20,7 +20,7 @@ for _ in range(reps):
     core.bvh_build()
     tot += core.stats()["buildMs"]
 out = {"n": n, "build_ms": round(tot / reps, 3), "mtris_per_s": round(n / (tot / reps) / 1e3, 1)}
-for k in ("k_calculate", "k_sort_hist", "k_sort_scatter", "k_scan", "k_dedup", "k_tree", "k_fit", "k_pack_leaves"):
+for k in ("k_calculate", "k_sort_hist", "k_sort_scatter", "k_scan", "k_dedup", "k_tree", "k_fit", "k_rotate", "k_emit_nodes", "k_fine_keys", "k_quantise", "k_pack_leaves", "k_visit_rank"):
     ms, cnt = core.kernel_time(k)
     out[k] = {"ms": round(ms / reps, 3), "launches": cnt // reps}
 print(json.dumps(out))
