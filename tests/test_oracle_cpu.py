@@ -434,6 +434,24 @@ def test_walk_tree_and_visit_rank(oracle):
     assert sorted(kids.tolist()) == list(range(1, n - 1)) + list(range(n, 2 * n))
     # boxes of the second tree enclose their triangles: the root boxes of both trees are the same union
     assert walk["bvh_data"][0].tobytes() == ref["bvh_data"][0].tobytes()
+    # after the tree rotations every box is still the union of its children's, and the parent links follow the child links
+    tri = ref["tri_aabb"][walk["sorted_index"]]
+    inner = walk["internal"]
+
+    def child_boxes(side):
+        leaf = inner[side + "NodeType"] != 0
+        idx = inner[side + "Node"]
+        mn = np.where(leaf[:, None], tri["min"][np.minimum(idx, n - 1)], walk["bvh_data"]["min"][np.minimum(idx, n - 2)])
+        mx = np.where(leaf[:, None], tri["max"][np.minimum(idx, n - 1)], walk["bvh_data"]["max"][np.minimum(idx, n - 2)])
+        return leaf, idx, mn, mx
+
+    lleaf, lidx, lmn, lmx = child_boxes("left")
+    rleaf, ridx, rmn, rmx = child_boxes("right")
+    assert np.array_equal(np.minimum(lmn, rmn), walk["bvh_data"]["min"]) and np.array_equal(np.maximum(lmx, rmx), walk["bvh_data"]["max"])
+    me = np.arange(n - 1)
+    for leaf, idx in ((lleaf, lidx), (rleaf, ridx)):
+        assert (walk["leaves"]["parent"][idx[leaf]] == me[leaf]).all()
+        assert (inner["parent"][idx[~leaf]] == me[~leaf]).all()
     # rank: recursive statement of the visiting order
     import sys
     sys.setrecursionlimit(10000)
