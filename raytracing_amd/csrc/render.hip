@@ -255,11 +255,17 @@ __global__ __launch_bounds__(Q_THREADS) void k_generate(RtTileMap tm, RtParams P
     const uint32_t total = tm.nSlots * nFrames;
 #pragma unroll 1
     for (int it = 0; it < Q_ITEMS; ++it) {
-        const uint32_t g = blockIdx.x * Q_TILE + it * Q_THREADS + threadIdx.x;
-        const uint32_t frame = g / tm.nSlots, slot = g - frame * tm.nSlots;
+        // Thread q makes path g = frame * nSlots + slot with (8x8-pixel block, frame, lane) read off q in that
+        // order, so the queue holds a pixel block's rays of ALL frames in flight next to each other: the waves
+        // that walk them at about the same time fetch the same nodes and triangles (frame-major order meets a
+        // pixel block again only a whole frame of rays later).  nSlots is a multiple of 64.
+        const uint32_t q = blockIdx.x * Q_TILE + it * Q_THREADS + threadIdx.x;
+        const uint32_t wave = q >> 6;
+        const uint32_t frame = wave % nFrames, slot = (wave / nFrames) * 64u + (q & 63u);
+        const uint32_t g = q < total ? frame * tm.nSlots + slot : RT_INVALID;
         uint32_t px = 0, py = 0;
-        const bool active = g < total && tm.slot_to_pixel(slot, &px, &py);
-        if (g < total && (CLEAR_RT || !active)) img[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const bool active = q < total && tm.slot_to_pixel(slot, &px, &py);
+        if (q < total && (CLEAR_RT || !active)) img[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (active) {
             rt_rng r;
             rt_rng_init(&r, px, py, seeds[frame]);
