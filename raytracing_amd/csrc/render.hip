@@ -895,8 +895,7 @@ static int overlap_fork(RtContext *ctx, const RtSceneView &sceneView, uint32_t t
     uint32_t blocks = ((uint32_t)ctx->numCU - ctx->overlapCUs) * walker_blocks_per_cu();
     const uint32_t need = (total * 16u + TRV_THREADS - 1) / TRV_THREADS;
     if (need < blocks) blocks = need ? need : 1;
-    if (ctx->countersOn) hipLaunchKernelGGL((k_traverse<true, ShadowSrcOverlapped>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->streamShadow, sv, sh, ctx->dQCount + CNT_FETCH_SM1);
-    else hipLaunchKernelGGL((k_traverse<false, ShadowSrcOverlapped>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->streamShadow, sv, sh, ctx->dQCount + CNT_FETCH_SM1);
+    hipLaunchKernelGGL((k_traverse<false, ShadowSrcOverlapped>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->streamShadow, sv, sh, ctx->dQCount + CNT_FETCH_SM1);
     RT_HIP(ctx, hipEventRecord(ctx->evJoin, ctx->streamShadow));
     ctx->streamMain = ctx->stream;
     ctx->stream = ctx->streamChain;
@@ -918,8 +917,7 @@ static int overlap_join(RtContext *ctx, const RtSceneView &sceneView, uint32_t t
     uint32_t blocks = ctx->overlapCUs * walker_blocks_per_cu();
     const uint32_t need = (total * 16u + TRV_THREADS - 1) / TRV_THREADS;
     if (need < blocks) blocks = need ? need : 1;
-    if (ctx->countersOn) hipLaunchKernelGGL((k_traverse<true, ShadowSrcOverlapped>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, sh, ctx->dQCount + CNT_FETCH_SM1);
-    else hipLaunchKernelGGL((k_traverse<false, ShadowSrcOverlapped>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, sh, ctx->dQCount + CNT_FETCH_SM1);
+    hipLaunchKernelGGL((k_traverse<false, ShadowSrcOverlapped>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, sh, ctx->dQCount + CNT_FETCH_SM1);
     RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evJoin, 0));
     launch_sm_resolve(ctx, total);
     return RT_OK;

@@ -19,7 +19,8 @@
 //     triangle the reference meets first win among exactly equal distances
 //     (leafRank), returns the same hit, bit for bit.  The one-ray-per-lane walker
 //     therefore walks a second tree, built from finer keys than the reference's
-//     (include/rt_finekey.h), through 32-byte nodes whose child boxes are rounded
+//     (include/rt_finekey.h) and reshaped by tree rotations (include/rt_rotate.h),
+//     through 32-byte nodes whose child boxes are rounded
 //     OUTWARD onto a 16-bit grid (rt_q16.h), with a cheap test that may say "maybe"
 //     but never a wrong "no"; the triangle's own box is exact and gets the
 //     reference's test.  Rays outside the monotone case (a zero / infinite / NaN
@@ -32,7 +33,10 @@
 //   * a wave keeps fetching new rays for lanes whose ray has finished
 //     (ballot + prefix count + one atomic per refill), and triangle tests are
 //     queued per lane in LDS and run in batches, in per-ray order, so that the
-//     64 lanes stay busy although rays take very different walks.
+//     64 lanes stay busy although rays take very different walks;
+//   * a ray source may declare that all it needs is WHETHER a hit of a certain kind exists
+//     (Src::FIRST_HIT_MAY_DECIDE, the ShadowMap pass's rays): a ray for which the source can
+//     show that its first accepted hit settles that ends its walk there.
 #ifndef RT_TRAVERSE_H_
 #define RT_TRAVERSE_H_
 
@@ -56,7 +60,9 @@
 #define TRV_DONE 0xFFFFFFFFu
 #define TRV_LDS_WORDS ((TRV_STACK_LDS + TRV_PEND_CAP) * TRV_THREADS)
 static_assert(TRV_LDS_WORDS * 4 * 6 <= 160 * 1024, "six blocks per CU must fit the LDS");
-#define TRV_BLOCKS_PER_CU 8u    // 20 KB of LDS per block: eight blocks fill a CU's 160 KB (registers allow six)
+#define TRV_BLOCKS_PER_CU 8u    // blocks launched per CU; five are resident at a time (88-96 registers per lane, 26 KB of LDS per
+                                // block), the others start when those end and find the queue empty (a grid of exactly
+                                // 5 per CU runs as fast, 7/8 of that 6 % slower)
 
 // The reference's slab test, verbatim: true divisions, min/max that return the
 // non-NaN operand (v_min_f32 / v_max_f32 in IEEE mode).
