@@ -335,13 +335,15 @@ __global__ __launch_bounds__(256) void k_tree(const uint32_t *__restrict__ codes
 // is < iter), so every read of a child box is ordered by a kernel boundary and
 // no atomics or fences are needed.  The union itself is min/max only, hence
 // identical to the reference's atomic-flag walk whatever the order.
-__global__ __launch_bounds__(256) void k_fit(uint32_t N, uint32_t iter, const uint32_t *__restrict__ left,
+// (`list`: the nodes still to do, nullptr = all n of them; see compact_undone)
+__global__ __launch_bounds__(256) void k_fit(uint32_t n, const uint32_t *__restrict__ list, uint32_t iter, const uint32_t *__restrict__ left,
                                               const uint32_t *__restrict__ right, const uint32_t *__restrict__ sortedIdx,
                                               const float4 *__restrict__ triAABB, float4 *bvhData, uint32_t *done,
                                               float4 *__restrict__ nodes)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N - 1) return;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t i = list ? list[k] : k;
     if (done[i] != FIT_UNDONE) return;
     const uint32_t l = left[i], r = right[i];
     const bool lLeaf = l & RT_LEAF_BIT, rLeaf = r & RT_LEAF_BIT;
@@ -360,6 +362,55 @@ __global__ __launch_bounds__(256) void k_fit(uint32_t N, uint32_t iter, const ui
     nodes[i * 4 + 2] = make_float4(rmn.z, rmx.x, rmx.y, rmx.z);
     nodes[i * 4 + 3] = make_float4(__uint_as_float(l), __uint_as_float(r), 0.0f, 0.0f);
     done[i] = iter;
+}
+
+// A level-synchronous pass looks at every node in every launch although half of the nodes are done after the
+// first launch and seven eighths after the third.  From then on the launches run over a list of the nodes
+// still to do, renewed every few levels (the order of the list does not matter).
+#define COMPACT_THREADS 1024
+__global__ __launch_bounds__(COMPACT_THREADS) void k_compact_undone(uint32_t n, const uint32_t *__restrict__ listIn,
+                                                                    const uint32_t *__restrict__ done, uint32_t *__restrict__ listOut,
+                                                                    uint32_t *__restrict__ count)
+{
+    __shared__ uint32_t waveBase[COMPACT_THREADS / 64];
+    __shared__ uint32_t blockBase;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = k < n ? (listIn ? listIn[k] : k) : 0u;
+    const bool keep = k < n && done[i] == FIT_UNDONE;
+    const unsigned long long m = __ballot(keep);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) waveBase[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {          // one atomic per block: atomics on one word are served one at a time
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < COMPACT_THREADS / 64; ++w) {
+            const uint32_t c = waveBase[w];
+            waveBase[w] = total;
+            total += c;
+        }
+        blockBase = total ? atomicAdd(count, total) : 0u;
+    }
+    __syncthreads();
+    if (keep) listOut[blockBase + waveBase[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+
+struct UndoneList {             // host side of the above: two lists that take turns, the count on the device and here
+    uint32_t *buf[2] = {nullptr, nullptr}, *dCount = nullptr;
+    const uint32_t *cur = nullptr;
+    uint32_t n = 0;
+    int which = 0;
+};
+
+static int compact_undone(RtContext *ctx, UndoneList &u, const uint32_t *done)
+{
+    hipStream_t st = ctx->stream;
+    RT_HIP(ctx, hipMemsetAsync(u.dCount, 0, 4, st));
+    if (u.n) hipLaunchKernelGGL(k_compact_undone, dim3((u.n + COMPACT_THREADS - 1) / COMPACT_THREADS), dim3(COMPACT_THREADS), 0, st, u.n, u.cur, done, u.buf[u.which], u.dCount);
+    RT_HIP(ctx, hipMemcpyAsync(&u.n, u.dCount, 4, hipMemcpyDeviceToHost, st));
+    RT_HIP(ctx, hipStreamSynchronize(st));
+    u.cur = u.buf[u.which];
+    u.which ^= 1;
+    return RT_OK;
 }
 
 // ------------------------------------------------------------------ tree rotations (traversal tree only)
@@ -382,12 +433,13 @@ __device__ __forceinline__ void load_box(uint32_t child, const uint32_t *__restr
     out[0] = mn.x; out[1] = mn.y; out[2] = mn.z; out[3] = mx.x; out[4] = mx.y; out[5] = mx.z;
 }
 
-__global__ __launch_bounds__(256) void k_rotate(uint32_t N, uint32_t iter, uint32_t *left, uint32_t *right,
+__global__ __launch_bounds__(256) void k_rotate(uint32_t n, const uint32_t *__restrict__ list, uint32_t iter, uint32_t *left, uint32_t *right,
                                                  const uint32_t *__restrict__ sortedIdx, const float4 *__restrict__ triAABB,
                                                  float4 *bvhData, uint32_t *done)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N - 1) return;
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t i = list ? list[k] : k;
     if (done[i] != FIT_UNDONE) return;
     const uint32_t l = left[i], r = right[i];
     const bool lInt = !(l & RT_LEAF_BIT), rInt = !(r & RT_LEAF_BIT);
@@ -647,8 +699,31 @@ static hipError_t dalloc(T **p, size_t count)
 // Scratch shared by the two passes of the pipeline.
 struct BuildScratch {
     uint32_t *keysB = nullptr, *valsB = nullptr, *blockHist = nullptr, *scanSums = nullptr, *done = nullptr;
+    uint32_t *undone[2] = {nullptr, nullptr}, *undoneCount = nullptr;
     uint32_t nbSort = 0, histLen = 0;
 };
+
+// One bottom-up pass over the NI internal nodes: launch(n, list, iter) until no node is left undone.
+template <class Launch>
+static int run_levels(RtContext *ctx, BuildScratch &sc, uint32_t NI, const char *what, Launch launch)
+{
+    RT_HIP(ctx, hipMemsetAsync(sc.done, 0xFF, (size_t)NI * 4, ctx->stream));
+    UndoneList u;
+    u.buf[0] = sc.undone[0];
+    u.buf[1] = sc.undone[1];
+    u.dCount = sc.undoneCount;
+    u.n = NI;
+    // A Karras tree over unique 32-bit keys is at most 32 levels high; rotations can add a level per pass.
+    for (uint32_t iter = 0; u.n; ++iter) {
+        if (iter >= 4096) return rt_fail(ctx, RT_E_STATE, "%s did not reach the root", what);
+        launch(u.n, u.cur, iter);
+        if (iter == 2 || (iter > 2 && (iter - 2) % 6 == 0)) {
+            const int rc = compact_undone(ctx, u, sc.done);
+            if (rc) return rc;
+        }
+    }
+    return RT_OK;
+}
 
 // sort -> duplicate-key spreading -> Karras tree -> bottom-up fit, on keys already in keysRaw / ids in sortedIdx.
 // Outputs: keysRaw (sorted), sortedIdx, codes (unique), left/right/parent/leafParent, bvhData, nodes (exact 64-byte nodes).
@@ -684,24 +759,12 @@ static int build_tree_from_keys(RtContext *ctx, BuildScratch &sc, uint32_t N, ui
     rt_timer_begin(ctx, "k_tree");
     hipLaunchKernelGGL(k_tree, gridNI, blk, 0, st, codes, N, left, right, parent, leafParent, rangeSize);
     rt_timer_end(ctx);
-    RT_HIP(ctx, hipMemsetAsync(sc.done, 0xFF, (size_t)NI * 4, st));
-    uint32_t rootDone = FIT_UNDONE;
-    // Tree height <= 32 (strictly growing common prefix of unique 32-bit keys).  The root is
-    // the last node to complete; look at its word every 8 levels to stop early.
-    for (uint32_t iter = 0; iter < 40 && rootDone == FIT_UNDONE; ++iter) {
+    return run_levels(ctx, sc, NI, "BVH fit", [&](uint32_t n, const uint32_t *list, uint32_t iter) {
         rt_timer_begin(ctx, "k_fit");
-        hipLaunchKernelGGL(k_fit, gridNI, blk, 0, st, N, iter, left, right, sortedIdx, (const float4 *)ctx->dTriAABB, (float4 *)bvhData, sc.done,
-                           (float4 *)nodes);
+        hipLaunchKernelGGL(k_fit, dim3((n + 255) / 256), blk, 0, st, n, list, iter, left, right, sortedIdx, (const float4 *)ctx->dTriAABB,
+                           (float4 *)bvhData, sc.done, (float4 *)nodes);
         rt_timer_end(ctx);
-        if ((iter & 7u) == 7u) {
-            RT_HIP(ctx, hipMemcpyAsync(&rootDone, sc.done, 4, hipMemcpyDeviceToHost, st));
-            RT_HIP(ctx, hipStreamSynchronize(st));
-        }
-    }
-    RT_HIP(ctx, hipMemcpyAsync(&rootDone, sc.done, 4, hipMemcpyDeviceToHost, st));
-    RT_HIP(ctx, hipStreamSynchronize(st));
-    if (rootDone == FIT_UNDONE) return rt_fail(ctx, RT_E_STATE, "BVH fit did not converge");
-    return RT_OK;
+    });
 }
 
 int rt_build_impl(RtContext *ctx)
@@ -744,6 +807,9 @@ int rt_build_impl(RtContext *ctx)
     RT_HIP(ctx, dalloc(&sc.blockHist, (size_t)sc.histLen));
     RT_HIP(ctx, dalloc(&sc.scanSums, (size_t)nbScanMax + 1));
     RT_HIP(ctx, dalloc(&sc.done, (size_t)NI));
+    RT_HIP(ctx, dalloc(&sc.undone[0], (size_t)NI));
+    RT_HIP(ctx, dalloc(&sc.undone[1], (size_t)NI));
+    RT_HIP(ctx, dalloc(&sc.undoneCount, (size_t)1));
     RT_HIP(ctx, dalloc(&wKeys, (size_t)N));
     RT_HIP(ctx, dalloc(&wCodes, (size_t)N));
     RT_HIP(ctx, dalloc(&wSortedIdx, (size_t)N));
@@ -791,22 +857,14 @@ int rt_build_impl(RtContext *ctx)
             return rc;
         if (N >= 3) {
             for (int pass = 0; pass < RT_ROTATION_PASSES; ++pass) {
-                RT_HIP(ctx, hipMemsetAsync(sc.done, 0xFF, (size_t)NI * 4, st));
-                uint32_t rootDone = FIT_UNDONE;
                 // a rotation can lengthen a path by one level, so the height is no longer bounded by the key width
-                for (uint32_t iter = 0; iter < 4096 && rootDone == FIT_UNDONE; ++iter) {
+                rc = run_levels(ctx, sc, NI, "tree rotation pass", [&](uint32_t n, const uint32_t *list, uint32_t iter) {
                     rt_timer_begin(ctx, "k_rotate");
-                    hipLaunchKernelGGL(k_rotate, gridNI, blk, 0, st, N, iter, wLeft, wRight, wSortedIdx, (const float4 *)ctx->dTriAABB,
-                                       (float4 *)wBvhData, sc.done);
+                    hipLaunchKernelGGL(k_rotate, dim3((n + 255) / 256), blk, 0, st, n, list, iter, wLeft, wRight, wSortedIdx,
+                                       (const float4 *)ctx->dTriAABB, (float4 *)wBvhData, sc.done);
                     rt_timer_end(ctx);
-                    if ((iter & 7u) == 7u) {
-                        RT_HIP(ctx, hipMemcpyAsync(&rootDone, sc.done, 4, hipMemcpyDeviceToHost, st));
-                        RT_HIP(ctx, hipStreamSynchronize(st));
-                    }
-                }
-                RT_HIP(ctx, hipMemcpyAsync(&rootDone, sc.done, 4, hipMemcpyDeviceToHost, st));
-                RT_HIP(ctx, hipStreamSynchronize(st));
-                if (rootDone == FIT_UNDONE) return rt_fail(ctx, RT_E_STATE, "tree rotation pass did not reach the root");
+                });
+                if (rc) return rc;
             }
             rt_timer_begin(ctx, "k_emit_nodes");
             hipLaunchKernelGGL(k_emit_nodes, gridNI, blk, 0, st, N, wLeft, wRight, wSortedIdx, (const float4 *)ctx->dTriAABB,
@@ -844,7 +902,7 @@ int rt_build_impl(RtContext *ctx)
     ctx->buildMs = ms;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    void *scratch[] = {sc.keysB, sc.valsB, sc.blockHist, sc.scanSums, sc.done, wKeys, wCodes, wSortedIdx, wLeft, wRight, wParent,
+    void *scratch[] = {sc.keysB, sc.valsB, sc.blockHist, sc.scanSums, sc.done, sc.undone[0], sc.undone[1], sc.undoneCount, wKeys, wCodes, wSortedIdx, wLeft, wRight, wParent,
                        wLeafParent, refSize, walkLeafOfTri, wBvhData, wNodes};
     for (void *q : scratch) (void)hipFree(q);
     ctx->built = true;
