@@ -285,6 +285,30 @@ def test_config4_car_4k_eight_tile_sets_make_the_whole_frame(core):
     assert covered.all()
 
 
+def test_car_1080p_execution_options_do_not_change_a_bit(core):
+    """The bench workload at full size, 16 frames in flight: shadow rays that end at their first hit, the ShadowMap
+    pass walked while the later bounces run on masked streams, material-sorted shading and the frame-interleaved ray
+    queue against the plain settings (closest-hit shadow rays, one launch after the other, two batches of 8)."""
+    sc = scenes.car_standin(1920, 1080)
+    seeds = scenes.frame_seeds(16, seed=3)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(sc.params)
+    images = []
+    for fast in (0, 1):
+        core.set_option(wire.OPT_FIRST_HIT_SHADOW, fast)
+        core.set_option(wire.OPT_OVERLAP_SHADOW, fast)
+        core.set_option(wire.OPT_MATERIAL_SORT, fast)
+        core.set_option(wire.OPT_BATCH_FRAMES, 0 if fast else 8)
+        core.set_dirty()
+        core.render_frames(seeds)
+        images.append((core.readback(wire.IMAGE_CONVERGED), core.readback(wire.IMAGE_SHADOWMAP), core.readback(wire.IMAGE_RT)))
+    core.set_option(wire.OPT_BATCH_FRAMES, 0)
+    for k, what in enumerate(("converged image", "shadow map of the last frame", "last frame")):
+        H.assert_bits_equal(images[0][k], images[1][k], what)
+    assert (images[0][1][..., 0] < 1).any()
+
+
 @pytest.mark.parametrize("scene,image,median_max,within8_min", [
     ("chapter6_3", "cornellbox", 4.0, 0.80),       # MIS, one area light, glass / mirror / clear-coat objects, teapot + round boxes
     ("chapter6_4", "mis", 4.0, 0.88),              # MIS, 20 sphere lights over five plates of rising smoothness
