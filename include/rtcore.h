@@ -384,12 +384,13 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *                          are walked WHILE the later bounces run: one launch on a stream masked to all compute units but
  *                          a few, the remaining bounce and shading launches on a stream masked to those few, a last launch
  *                          that drains the same queue afterwards.  Same results bit for bit (a ray's result does not
- *                          depend on which launch walks it); 2 % faster for a whole 1080p image of the car scene, 10 %
+ *                          depend on which launch walks it); 4 % faster for a whole 1080p image of the car scene, 17 %
  *                          for an eighth of it.  Off while counters or kernel timing are enabled (they report launches
  *                          one by one), with RT_OPT_PACKET_SHADOW, RT_OPT_TWO_STREAMS or the brute-force flag, and where
  *                          the runtime cannot make masked streams.
- *   RT_OPT_OVERLAP_AFTER   0..6, default 1: the bounce whose extend launch the overlap starts after
- *   RT_OPT_OVERLAP_CUS     compute units the bounce launches keep meanwhile, default 32 (multiples of 32 measured best);
+ *   RT_OPT_OVERLAP_AFTER   0..6, default 0: the bounce whose extend launch the overlap starts after (0: as soon as the
+ *                          primary hits are known)
+ *   RT_OPT_OVERLAP_CUS     compute units the bounce launches keep meanwhile, default 64 (multiples of 32 measured best);
  *                          read when a context first renders that way, and the contexts of a process that render on the
  *                          same device share the first one's split */
 #define RT_OPT_PACKET_SHADOW 0

@@ -211,8 +211,8 @@ struct RtContext {
     RtAABB nonCasterBox = {{0, 0, 0}, 0, {0, 0, 0}, 0};   // round the triangles whose castShadow flag is not set (rt_scene_upload)
     bool optFirstHitShadow = true;        // shadow rays that cannot meet a non-casting triangle stop at their first hit
     bool optOverlapShadow = true;         // walk the shadow rays while the later bounces run (render.hip, overlap_fork)
-    uint32_t optOverlapAfter = 1;         // ... from the extend launch of this bounce on
-    uint32_t optOverlapCUs = 32;          // compute units the bounce launches keep meanwhile
+    uint32_t optOverlapAfter = 0;         // ... from the extend launch of this bounce on
+    uint32_t optOverlapCUs = 64;          // compute units the bounce launches keep meanwhile
     uint32_t optBatchFrames = 0;          // 0 = by path count (rt_batch_frames)
     uint32_t batchCap = 0;                // frames the path-state buffers can hold
     uint32_t lastFrame = 0;               // frame of the batch that RT_IMAGE_RT / RT_IMAGE_SHADOWMAP show

@@ -284,7 +284,7 @@ def test_shadow_rays_walked_while_the_bounces_run_do_not_change_a_bit(core):
             core.render_frames(seeds)
         images.append((core.readback(wire.IMAGE_CONVERGED), core.readback(wire.IMAGE_SHADOWMAP)))
     core.set_option(wire.OPT_OVERLAP_SHADOW, 1)
-    core.set_option(wire.OPT_OVERLAP_AFTER, 1)
+    core.set_option(wire.OPT_OVERLAP_AFTER, 0)
     assert (images[0][1][..., 0] < 1).any() and (images[0][1][..., 0] == 1).any()
     for k in range(1, len(images)):
         H.assert_bits_equal(images[0][0], images[k][0], f"converged image, overlap variant {k}")
