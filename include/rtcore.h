@@ -384,7 +384,7 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *                          are walked WHILE the later bounces run: one launch on a stream masked to all compute units but
  *                          a few, the remaining bounce and shading launches on a stream masked to those few, a last launch
  *                          that drains the same queue afterwards.  Same results bit for bit (a ray's result does not
- *                          depend on which launch walks it); 4 % faster for a whole 1080p image of the car scene, 17 %
+ *                          depend on which launch walks it); 6 % faster for a whole 1080p image of the car scene, 21 %
  *                          for an eighth of it.  Off while counters or kernel timing are enabled (they report launches
  *                          one by one), with RT_OPT_PACKET_SHADOW, RT_OPT_TWO_STREAMS or the brute-force flag, and where
  *                          the runtime cannot make masked streams.
