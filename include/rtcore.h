@@ -380,6 +380,9 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *   RT_OPT_FIRST_HIT_SHADOW 1 (default): a ShadowMap ray only reports whether its closest hit casts a shadow, so a ray
  *                          that stays clear of the box round the scene's non-casting triangles (it can only meet casters)
  *                          ends its walk at the first hit it accepts.  Same shadow map bit for bit.
+ *   RT_OPT_CASTER_BOX      1 (default): a ShadowMap ray that stays clear of the box round the shadow-casting triangles is lit
+ *                          whatever else it meets; a pixel none of whose 16 rays passes that box gets no rays at all
+ *                          (its shadow-map value is what 16 misses give).  Same shadow map bit for bit.
  *   RT_OPT_OVERLAP_SHADOW  1 (default): in rt_render_frames, when the ShadowMap pass shares CSMain's primary hits, its rays
  *                          are walked WHILE the later bounces run: one launch on a stream masked to all compute units but
  *                          a few, the remaining bounce and shading launches on a stream masked to those few, a last launch
@@ -403,6 +406,7 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
 #define RT_OPT_OVERLAP_AFTER 7
 #define RT_OPT_OVERLAP_CUS 8
 #define RT_OPT_FIRST_HIT_SHADOW 9
+#define RT_OPT_CASTER_BOX 10
 int rt_set_option(RtContext *ctx, int option, int value);
 
 /* ------------------------------------------------------------------- stats */

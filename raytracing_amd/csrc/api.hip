@@ -175,25 +175,28 @@ int rt_scene_upload(RtContext *ctx, const RtMeshVertex *vertices, uint32_t n_ver
     if (n_triangles >= 0x7FFFFFFFu) return rt_fail(ctx, RT_E_INVALID, "too many triangles");
     for (uint32_t i = 0; i < n_indices; ++i)   // every index a kernel dereferences is checked here
         if (indices[i] >= n_vertices) return rt_fail(ctx, RT_E_INVALID, "index %u out of range at %u", indices[i], i);
-    // Box round the OWN BOXES (as the build makes them, k_calculate: vertex extremes -+ 0.001, the same float
-    // operations) of the triangles that cast no shadow (MeshData.compute:127 reads the flag from [0]); min > max: none.
+    // Boxes round the OWN BOXES (as the build makes them, k_calculate: vertex extremes -+ 0.001, the same float
+    // operations) of the triangles that cast no shadow and of those that do (MeshData.compute:127 reads the flag
+    // from [0]); min > max: none.
     // While they are few, their records as well, in the layout and with the float operations of k_pack_leaves.
-    RtAABB nc;
-    for (int a = 0; a < 3; ++a) nc.min[a] = rt_inf(), nc.max[a] = -rt_inf();
-    nc._dummy0 = nc._dummy1 = 0.0f;
+    RtAABB nc, ca;
+    for (int a = 0; a < 3; ++a) nc.min[a] = ca.min[a] = rt_inf(), nc.max[a] = ca.max[a] = -rt_inf();
+    nc._dummy0 = nc._dummy1 = ca._dummy0 = ca._dummy1 = 0.0f;
     float records[RT_NONCASTER_LIST][16];
     uint32_t nNc = 0;
     for (uint32_t t = 0; t < n_triangles; ++t) {
-        if (shadow_index_xy[2 * (size_t)t] > 0) continue;
+        const bool casts = shadow_index_xy[2 * (size_t)t] > 0;
+        RtAABB &box = casts ? ca : nc;
         const float *p0 = vertices[indices[3 * (size_t)t]].position, *p1 = vertices[indices[3 * (size_t)t + 1]].position,
                     *p2 = vertices[indices[3 * (size_t)t + 2]].position;
         float mn[3], mx[3];
         for (int a = 0; a < 3; ++a) {
             mn[a] = rt_min(rt_min(p0[a], p1[a]), p2[a]) - 0.001f;
             mx[a] = rt_max(rt_max(p0[a], p1[a]), p2[a]) + 0.001f;
-            if (!(mn[a] >= nc.min[a])) nc.min[a] = mn[a] == mn[a] ? mn[a] : -rt_inf();      // a NaN coordinate opens the box
-            if (!(mx[a] <= nc.max[a])) nc.max[a] = mx[a] == mx[a] ? mx[a] : rt_inf();
+            if (!(mn[a] >= box.min[a])) box.min[a] = mn[a] == mn[a] ? mn[a] : -rt_inf();      // a NaN coordinate opens the box
+            if (!(mx[a] <= box.max[a])) box.max[a] = mx[a] == mx[a] ? mx[a] : rt_inf();
         }
+        if (casts) continue;
         if (nNc < RT_NONCASTER_LIST) {
             const float rec[16] = {p0[0], p0[1], p0[2], p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2], p2[0] - p0[0], p2[1] - p0[1],
                                    p2[2] - p0[2], 0.0f, mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]};
@@ -206,6 +209,7 @@ int rt_scene_upload(RtContext *ctx, const RtMeshVertex *vertices, uint32_t n_ver
     if (nNc && nNc <= RT_NONCASTER_LIST)
         RT_HIP(ctx, hipMemcpy(ctx->dNonCasters, records, (size_t)nNc * 64, hipMemcpyHostToDevice));
     ctx->nonCasterBox = nc;
+    ctx->casterBox = ca;
     int rc;
     if ((rc = upload(ctx, &ctx->dVerts, vertices, n_vertices))) return rc;
     if ((rc = upload(ctx, &ctx->dIdx, indices, n_indices))) return rc;
@@ -563,6 +567,7 @@ int rt_set_option(RtContext *ctx, int option, int value)
     case RT_OPT_PACKET_TRACE: ctx->optPacketTrace = value != 0; return RT_OK;
     case RT_OPT_MATERIAL_SORT: ctx->optMaterialSort = value != 0; return RT_OK;
     case RT_OPT_TWO_STREAMS: ctx->optTwoStreams = value != 0; return RT_OK;
+    case RT_OPT_CASTER_BOX: ctx->optCasterBox = value != 0; return RT_OK;
     case RT_OPT_FIRST_HIT_SHADOW: ctx->optFirstHitShadow = value != 0; return RT_OK;
     case RT_OPT_OVERLAP_SHADOW: ctx->optOverlapShadow = value != 0; return RT_OK;
     case RT_OPT_OVERLAP_AFTER:

@@ -98,13 +98,39 @@ __constant__ float c_blue_noise[16][2] = {   // first 16 entries of BLUE_NOISE_I
     {-0.415667f, 0.323909f}, {0.141896f, -0.939980f},  {0.954932f, -0.182516f},  {-0.766184f, 0.410799f},
     {-0.434912f, -0.458845f}, {0.415242f, -0.078724f}, {0.728335f, -0.491777f},  {-0.058086f, -0.066401f}};
 
+// Direction of soft-shadow ray k of a pixel (Shadow.cginc:95-104): the blue-noise disk sample k, turned by the
+// pixel's random angle, scaled to the light's radius, laid round the light direction.
+struct ShadowFrame {
+    rt_f3 lightDir, lightTangent, lightBitangent;
+    float lightRadius;
+    // Box round the own (padded) boxes of the triangles that DO cast a shadow (min > max: none).  A ray that fails
+    // the reference's slab test on it is accepted by none of them -- the test is monotone in the box -- so its
+    // closest hit, if it has one, casts no shadow: the answer is "lit" without a walk.
+    float casterMin[3], casterMax[3];
+    __device__ __forceinline__ rt_f3 direction(uint32_t k, float cosTheta, float sinTheta) const
+    {
+        const float sx = c_blue_noise[k][0], sy = c_blue_noise[k][1];
+        float dx = sx * cosTheta - sy * sinTheta;
+        float dy = sx * sinTheta + sy * cosTheta;
+        dx *= lightRadius;
+        dy *= lightRadius;
+        return rt_normalize3(rt_add3(rt_add3(lightDir, rt_scale3(lightTangent, dx)), rt_scale3(lightBitangent, dy)));
+    }
+    __device__ __forceinline__ bool may_meet_a_caster(const rt_f3 o, const rt_f3 d) const
+    {
+        if (casterMin[0] > casterMax[0]) return false;
+        if (rt_ray_needs_exact_walk(o, d)) return true;
+        const rt_f3 r = rt_mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);     // box_hit: the reference's boolean, divisions only on a graze
+        return box_hit(casterMin[0], casterMin[1], casterMin[2], casterMax[0], casterMax[1], casterMax[2], o, d, r);
+    }
+};
+
 struct ShadowSrc {
     const uint32_t *smq, *smqCount;
     const float4 *rec;         // per slot: (origin.xyz, cosTheta), (sinTheta, ., ., .)
     uint8_t *flags;            // per slot x 16
     const RtLeafShade *leafShade;
-    rt_f3 lightDir, lightTangent, lightBitangent;
-    float lightRadius;
+    ShadowFrame frame;
     // All a shadow ray reports is whether its closest hit casts a shadow.  A ray that no NON-casting triangle
     // can accept only meets casters, so its first accepted hit settles the answer and the walk ends there.
     // Asked once per ray, when it first holds a hit: the ray is tested against the box round the own boxes
@@ -136,15 +162,11 @@ struct ShadowSrc {
     {
         const uint32_t slot = smq[i >> 4], k = i & 15u;
         const float4 a = rec[slot * 2], b = rec[slot * 2 + 1];
-        const float cosTheta = a.w, sinTheta = b.x;
-        const float sx = c_blue_noise[k][0], sy = c_blue_noise[k][1];
-        float dx = sx * cosTheta - sy * sinTheta;
-        float dy = sx * sinTheta + sy * cosTheta;
-        dx *= lightRadius;
-        dy *= lightRadius;
         o = rt_mk3(a.x, a.y, a.z);
-        d = rt_normalize3(rt_add3(rt_add3(lightDir, rt_scale3(lightTangent, dx)), rt_scale3(lightBitangent, dy)));
+        d = frame.direction(k, a.w, b.x);
     }
+    // (k_sm_setup leaves out the pixels none of whose 16 rays can meet a caster.  Asking the same of every ray of the
+    //  other pixels when it is fetched cost more than the few walks it saved.)
     __device__ __forceinline__ void store(uint32_t i, const RtHitRec &h) const
     {
         const uint32_t slot = smq[i >> 4], k = i & 15u;
@@ -440,7 +462,8 @@ __global__ __launch_bounds__(Q_THREADS) void k_sm_setup(RtSceneView sv, RtTileMa
                                                    const float4 *__restrict__ pd, const uint2 *__restrict__ rng,
                                                    const RtHitRec *__restrict__ hitRec, float4 *__restrict__ rec,
                                                    float4 *__restrict__ shadowMap, uint32_t *__restrict__ smq,
-                                                   uint32_t *__restrict__ smqCount)
+                                                   uint32_t *__restrict__ smqCount, ShadowFrame frame, int skipUnshadowable,
+                                                   unsigned long long *__restrict__ shadowRayCounter)
 {
     __shared__ uint32_t stage[Q_TILE];
     const uint32_t n = *qcount;
@@ -448,7 +471,7 @@ __global__ __launch_bounds__(Q_THREADS) void k_sm_setup(RtSceneView sv, RtTileMa
 #pragma unroll 1
     for (int it = 0; it < Q_ITEMS; ++it) {
     const uint32_t i = blockIdx.x * Q_TILE + it * Q_THREADS + threadIdx.x;
-    bool shaded = false;
+    bool shaded = false, skipped = false;
     uint32_t slot = 0;
     if (i < n) {
         slot = queue[i];
@@ -473,12 +496,30 @@ __global__ __launch_bounds__(Q_THREADS) void k_sm_setup(RtSceneView sv, RtTileMa
             const float theta = blueNoise * 2.0f * RT_PI;
             const float cosTheta = rt_cos(theta);
             const float sinTheta = rt_sin(theta);
+            const float alpha = hit.materialType == 4 ? 0.0f : 1.0f;
             rec[slot * 2 + 0] = make_float4(origin.x, origin.y, origin.z, cosTheta);
-            rec[slot * 2 + 1] = make_float4(sinTheta, hit.materialType == 4 ? 0.0f : 1.0f, 0.0f, 0.0f);
+            rec[slot * 2 + 1] = make_float4(sinTheta, alpha, 0.0f, 0.0f);
             shaded = true;
+            if (skipUnshadowable) {
+                // a pixel none of whose 16 rays can meet a shadow caster is lit: what k_sm_resolve makes of 16 misses
+                bool any = false;
+#pragma unroll 1
+                for (uint32_t k = 0; k < 16u && !any; ++k) any = frame.may_meet_a_caster(origin, frame.direction(k, cosTheta, sinTheta));
+                if (!any) {
+                    const rt_f3 lit = rt_lerp3(rt_splat3(1.0f), rt_mk3(P.shadowParameter[0], P.shadowParameter[1], P.shadowParameter[2]),
+                                               P.shadowParameter[3] * 0.0f);
+                    shadowMap[slot] = make_float4(lit.x, lit.y, lit.z, alpha);
+                    shaded = false;
+                    skipped = true;
+                }
+            }
         }
     }
     stage[it * Q_THREADS + threadIdx.x] = shaded ? slot : RT_INVALID;
+    if (shadowRayCounter) {     // counters on: the 16 rays of a pixel that got none are rays answered all the same
+        const unsigned long long m = __ballot(skipped);
+        if ((threadIdx.x & 63u) == 0 && m) atomicAdd(shadowRayCounter, 16ull * (unsigned long long)__popcll(m));
+    }
     }
     block_queue_flush(stage, smq, smqCount);
 }
@@ -752,28 +793,42 @@ static bool shadow_shares_primary(const RtParams &P)
     return ((P.flags & RT_FLAG_DOF_PRIMARY) != 0) == ((P.flags & RT_FLAG_DEPTH_OF_FIELD) != 0);
 }
 
+static ShadowFrame shadow_frame(RtContext *ctx);
+
 static void launch_sm_setup(RtContext *ctx, const RtSceneView &sv, uint32_t total, const uint32_t *queue, const uint32_t *qcount)
 {
     rt_timer_begin(ctx, "k_sm_setup");
     hipLaunchKernelGGL(k_sm_setup, dim3((total + Q_TILE - 1) / Q_TILE), dim3(Q_THREADS), 0, ctx->stream, sv, ctx->tile, ctx->params, queue, qcount,
-                       ctx->dPo, ctx->dPd, ctx->dRng, ctx->dHit, ctx->dSmRec, ctx->dShadowMap, ctx->dSmQueue, ctx->dQCount + CNT_SMQ);
+                       ctx->dPo, ctx->dPd, ctx->dRng, ctx->dHit, ctx->dSmRec, ctx->dShadowMap, ctx->dSmQueue, ctx->dQCount + CNT_SMQ,
+                       shadow_frame(ctx), ctx->optCasterBox ? 1 : 0, ctx->countersOn ? ctx->dStats + 32 : nullptr);
     rt_timer_end(ctx);
+}
+
+static ShadowFrame shadow_frame(RtContext *ctx)
+{
+    const RtParams &P = ctx->params;
+    ShadowFrame f;
+    // Shadow.cginc:92-93, evaluated once on the host with the same IEEE float operations
+    f.lightDir = rt_mk3(-P.lightParameter[0], -P.lightParameter[1], -P.lightParameter[2]);
+    f.lightTangent = rt_normalize3(rt_cross3(f.lightDir, rt_mk3(0.0f, 1.0f, 0.0f)));
+    f.lightBitangent = rt_normalize3(rt_cross3(f.lightTangent, f.lightDir));
+    f.lightRadius = P.lightParameter[3];
+    for (int a = 0; a < 3; ++a) {
+        f.casterMin[a] = ctx->optCasterBox ? ctx->casterBox.min[a] : -rt_inf();
+        f.casterMax[a] = ctx->optCasterBox ? ctx->casterBox.max[a] : rt_inf();
+    }
+    return f;
 }
 
 static ShadowSrc shadow_source(RtContext *ctx)
 {
-    const RtParams &P = ctx->params;
     ShadowSrc sh;
     sh.smq = ctx->dSmQueue;
     sh.smqCount = ctx->dQCount + CNT_SMQ;
     sh.rec = ctx->dSmRec;
     sh.flags = ctx->dSmFlags;
     sh.leafShade = ctx->dLeafShade;
-    // Shadow.cginc:92-93, evaluated once on the host with the same IEEE float operations
-    sh.lightDir = rt_mk3(-P.lightParameter[0], -P.lightParameter[1], -P.lightParameter[2]);
-    sh.lightTangent = rt_normalize3(rt_cross3(sh.lightDir, rt_mk3(0.0f, 1.0f, 0.0f)));
-    sh.lightBitangent = rt_normalize3(rt_cross3(sh.lightTangent, sh.lightDir));
-    sh.lightRadius = P.lightParameter[3];
+    sh.frame = shadow_frame(ctx);
     sh.ncTri = ctx->dNonCasters;
     sh.nNc = ctx->nNonCasters;
     for (int a = 0; a < 3; ++a) {

@@ -209,6 +209,8 @@ struct RtContext {
     float4 *dNonCasters = nullptr;        // leafTri-layout records of the non-casting triangles while they are at most RT_NONCASTER_LIST
     uint32_t nNonCasters = 0;
     RtAABB nonCasterBox = {{0, 0, 0}, 0, {0, 0, 0}, 0};   // round the triangles whose castShadow flag is not set (rt_scene_upload)
+    RtAABB casterBox = {{0, 0, 0}, 0, {0, 0, 0}, 0};      // round the own boxes of the triangles whose castShadow flag is set (rt_scene_upload)
+    bool optCasterBox = true;             // shadow rays that cannot meet a shadow caster are not walked
     bool optFirstHitShadow = true;        // shadow rays that cannot meet a non-casting triangle stop at their first hit
     bool optOverlapShadow = true;         // walk the shadow rays while the later bounces run (render.hip, overlap_fork)
     uint32_t optOverlapAfter = 0;         // ... from the extend launch of this bounce on

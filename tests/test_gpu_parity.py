@@ -326,13 +326,16 @@ def test_shadow_rays_that_stop_at_their_first_hit_do_not_change_a_bit(core, non_
     core.bvh_build()
     core.set_params(sc.params)
     images = []
-    for on in (0, 1):
-        core.set_option(wire.OPT_FIRST_HIT_SHADOW, on)
+    # (first hit decides, rays that cannot meet a caster are not walked): none, each alone, both
+    for first_hit, caster_box in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        core.set_option(wire.OPT_FIRST_HIT_SHADOW, first_hit)
+        core.set_option(wire.OPT_CASTER_BOX, caster_box)
         core.set_dirty()
         core.render_frames(seeds)
         images.append((core.readback(wire.IMAGE_CONVERGED), core.readback(wire.IMAGE_SHADOWMAP)))
-    H.assert_bits_equal(images[0][0], images[1][0], "converged image, first-hit shortcut off vs on")
-    H.assert_bits_equal(images[0][1], images[1][1], "shadow map, first-hit shortcut off vs on")
+    for k in (1, 2, 3):
+        H.assert_bits_equal(images[0][0], images[k][0], f"converged image, shadow-ray shortcuts, variant {k}")
+        H.assert_bits_equal(images[0][1], images[k][1], f"shadow map, shadow-ray shortcuts, variant {k}")
     if non_casters in ("ground only", "none", "a flat sheet under the car"):
         assert (images[0][1][..., 0] < 1).any()
     if non_casters == "all":

@@ -297,6 +297,7 @@ def test_car_1080p_execution_options_do_not_change_a_bit(core):
     images = []
     for fast in (0, 1):
         core.set_option(wire.OPT_FIRST_HIT_SHADOW, fast)
+        core.set_option(wire.OPT_CASTER_BOX, fast)
         core.set_option(wire.OPT_OVERLAP_SHADOW, fast)
         core.set_option(wire.OPT_MATERIAL_SORT, fast)
         core.set_option(wire.OPT_BATCH_FRAMES, 0 if fast else 8)
