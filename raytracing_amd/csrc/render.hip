@@ -116,6 +116,39 @@ struct ShadowFrame {
         dy *= lightRadius;
         return rt_normalize3(rt_add3(rt_add3(lightDir, rt_scale3(lightTangent, dx)), rt_scale3(lightBitangent, dy)));
     }
+    // A cheap sufficient test for "none of the 16 rays from o can meet a caster", in plain geometry: every ray
+    // direction lies within the angle atan(coneTan) of the central direction, so a point of such a ray inside the
+    // caster box, at most D from o (D = distance to the farthest corner), is within D * coneTan of the central ray; if
+    // the central ray misses the box grown by that much on every side, no ray of the cone touches the box.  The
+    // growth is taken 0.2 % of D larger than needed, thousands of times what rounding in the exact per-ray test
+    // can move a graze.  coneTan < 0: no such test (degenerate light direction or radius).
+    rt_f3 coneAxis;
+    float coneTan;
+    __device__ __forceinline__ bool cone_misses_the_casters(const rt_f3 o) const
+    {
+        if (!(coneTan >= 0.0f)) return false;
+        if (casterMin[0] > casterMax[0]) return true;
+        const float oc[3] = {o.x, o.y, o.z}, dc[3] = {coneAxis.x, coneAxis.y, coneAxis.z};
+        float far2 = 0.0f;
+        for (int a = 0; a < 3; ++a) {
+            const float e = rt_max(__builtin_fabsf(casterMin[a] - oc[a]), __builtin_fabsf(casterMax[a] - oc[a]));
+            far2 += e * e;
+        }
+        const float D = __builtin_sqrtf(far2);
+        const float grow = D * coneTan + D * 2.0e-3f + 1.0e-6f;
+        float tn = 0.0f, tf = rt_inf();
+        for (int a = 0; a < 3; ++a) {
+            const float lo = (casterMin[a] - grow) - oc[a], hi = (casterMax[a] + grow) - oc[a];
+            if (__builtin_fabsf(dc[a]) < 1.0e-12f) {
+                if (lo > 0.0f || hi < 0.0f) return true;
+            } else {
+                const float t1 = lo / dc[a], t2 = hi / dc[a];
+                tn = rt_max(tn, rt_min(t1, t2));
+                tf = rt_min(tf, rt_max(t1, t2));
+            }
+        }
+        return tn > tf;           // any NaN on the way makes this false: not a sure miss, the 16 rays are tested
+    }
     __device__ __forceinline__ bool may_meet_a_caster(const rt_f3 o, const rt_f3 d) const
     {
         if (casterMin[0] > casterMax[0]) return false;
@@ -503,8 +536,10 @@ __global__ __launch_bounds__(Q_THREADS) void k_sm_setup(RtSceneView sv, RtTileMa
             if (skipUnshadowable) {
                 // a pixel none of whose 16 rays can meet a shadow caster is lit: what k_sm_resolve makes of 16 misses
                 bool any = false;
+                if (!frame.cone_misses_the_casters(origin)) {
 #pragma unroll 1
-                for (uint32_t k = 0; k < 16u && !any; ++k) any = frame.may_meet_a_caster(origin, frame.direction(k, cosTheta, sinTheta));
+                    for (uint32_t k = 0; k < 16u && !any; ++k) any = frame.may_meet_a_caster(origin, frame.direction(k, cosTheta, sinTheta));
+                }
                 if (!any) {
                     const rt_f3 lit = rt_lerp3(rt_splat3(1.0f), rt_mk3(P.shadowParameter[0], P.shadowParameter[1], P.shadowParameter[2]),
                                                P.shadowParameter[3] * 0.0f);
@@ -817,6 +852,15 @@ static ShadowFrame shadow_frame(RtContext *ctx)
         f.casterMin[a] = ctx->optCasterBox ? ctx->casterBox.min[a] : -rt_inf();
         f.casterMax[a] = ctx->optCasterBox ? ctx->casterBox.max[a] : rt_inf();
     }
+    // the cone of the 16 directions: lightDir + (tangent, bitangent) * (disk sample * radius), the samples inside the
+    // unit disk, tangent and bitangent unit vectors at right angles to lightDir
+    const float len = sqrtf(rt_dot3(f.lightDir, f.lightDir));
+    f.coneAxis = rt_scale3(f.lightDir, 1.0f / len);
+    f.coneTan = fabsf(f.lightRadius) / len * 1.001f;
+    const float ortho = fabsf(rt_dot3(f.lightTangent, f.lightDir)) + fabsf(rt_dot3(f.lightBitangent, f.lightDir)) +
+                        fabsf(rt_dot3(f.lightTangent, f.lightBitangent));
+    const bool unit = fabsf(rt_dot3(f.lightTangent, f.lightTangent) - 1.0f) < 1e-3f && fabsf(rt_dot3(f.lightBitangent, f.lightBitangent) - 1.0f) < 1e-3f;
+    if (!(len > 1e-6f && len < 1e6f && f.coneTan < 10.0f && unit && ortho < 1e-3f * (1.0f + len))) f.coneTan = -1.0f;
     return f;
 }
 

@@ -291,7 +291,8 @@ def test_shadow_rays_walked_while_the_bounces_run_do_not_change_a_bit(core):
         H.assert_bits_equal(images[0][1], images[k][1], f"shadow map, overlap variant {k}")
 
 
-@pytest.mark.parametrize("non_casters", ["ground only", "a third of the car", "none", "all", "a flat sheet under the car"])
+@pytest.mark.parametrize("non_casters", ["ground only", "a third of the car", "none", "all", "a flat sheet under the car",
+                                         "ground only, light in the xy plane", "ground only, wide light"])
 def test_shadow_rays_that_stop_at_their_first_hit_do_not_change_a_bit(core, non_casters):
     """A ShadowMap ray that stays clear of the box round the non-casting triangles ends at its first accepted hit;
     the shadow map is the one of the full closest-hit walk, wherever the non-casters are."""
@@ -321,6 +322,14 @@ def test_shadow_rays_that_stop_at_their_first_hit_do_not_change_a_bit(core, non_
     elif non_casters == "all":
         sh[:, 0] = 0
     sc.shadow_index = sh
+    if non_casters == "ground only, light in the xy plane":      # a direction component that is exactly zero
+        p = sc.params.copy()
+        p.lightParameter[0], p.lightParameter[1], p.lightParameter[2] = -0.6, -0.8, 0.0
+        sc.params = p
+    if non_casters == "ground only, wide light":                 # a wide cone of shadow-ray directions
+        p = sc.params.copy()
+        p.lightParameter[3] = 1.5
+        sc.params = p
     seeds = scenes.frame_seeds(4, seed=13)
     core.upload(sc)
     core.bvh_build()
@@ -336,7 +345,7 @@ def test_shadow_rays_that_stop_at_their_first_hit_do_not_change_a_bit(core, non_
     for k in (1, 2, 3):
         H.assert_bits_equal(images[0][0], images[k][0], f"converged image, shadow-ray shortcuts, variant {k}")
         H.assert_bits_equal(images[0][1], images[k][1], f"shadow map, shadow-ray shortcuts, variant {k}")
-    if non_casters in ("ground only", "none", "a flat sheet under the car"):
+    if non_casters in ("ground only", "none", "a flat sheet under the car") or non_casters.startswith("ground only,"):
         assert (images[0][1][..., 0] < 1).any()
     if non_casters == "all":
         assert (images[0][1][..., :3] == 1).all()
