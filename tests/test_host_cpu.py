@@ -33,6 +33,20 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.rt_version()
 
 
+def test_python_constants_follow_the_header():
+    """Option numbers, flags and image selectors of raytracing_amd.wire are the header's."""
+    txt = open(os.path.join(ROOT, "include", "rtcore.h")).read()
+    defines = {k: int(v, 0) for k, v in re.findall(r"^#define\s+(RT_[A-Z_0-9]+)\s+(0x[0-9A-Fa-f]+|\d+)u?\s*$", txt, flags=re.M)}
+    options = {k[len("RT_"):]: v for k, v in defines.items() if k.startswith("RT_OPT_")}
+    assert len(options) >= 11
+    for name, value in options.items():
+        assert getattr(wire, name) == value, name
+    for name in ("FLAG_BRUTE_FORCE", "FLAG_MATTE_MASK", "FLAG_DEPTH_OF_FIELD", "FLAG_DOF_PRIMARY", "IMAGE_CONVERGED", "IMAGE_RT",
+                 "IMAGE_SHADOWMAP", "IMAGE_POSTPROCESS", "IMAGE_USER"):
+        if "RT_" + name in defines:
+            assert getattr(wire, name) == defines["RT_" + name], name
+
+
 def test_no_gpu_means_error_code_not_crash():
     import torch
     if torch.cuda.is_available():
