@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the rtcore hot path on N MI355X of one node.
 
-Workload (BASELINE.json metric): the car scene (procedural stand-in, the real
+Workload (the headline metric of this project): the car scene (procedural stand-in, the real
 mesh and HDRIs are absent from the reference checkout), 1920x1080, 64 samples
 per pixel.  One STEP = one finished 64-spp image = 64 x { CSMain dispatch,
 ShadowMap dispatch, accumulate } = 64 calls of the reference's CustomRender

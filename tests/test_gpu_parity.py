@@ -1,6 +1,6 @@
 """GPU parity tests: the HIP library (through its C ABI) against the CPU checker
 on the same seeded inputs.  Integer / index / box outputs must be bit-exact;
-radiance must agree to per-pixel relative L2 <= 1e-3 (BASELINE north star)."""
+radiance must agree to per-pixel relative L2 <= 1e-3."""
 import numpy as np
 import pytest
 

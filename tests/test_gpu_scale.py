@@ -1,4 +1,4 @@
-"""GPU tests at BASELINE's full sizes plus the host-mirror drive.  At 10 M
+"""GPU tests at the full sizes of the named configurations plus the host-mirror drive.  At 10 M
 triangles the whole build is still compared bit for bit with the CPU checker
 (which builds it in a few seconds) and, independently, through size-free
 properties: sortedness, permutation, stability, strictly increasing keys,
@@ -149,7 +149,7 @@ def test_traversal_stress_10m(core, oracle, soup10m):
     print(f"\n10M soup: {n} incoherent rays in {ms:.2f} ms = {n / ms / 1e3:.1f} Mrays/s")
 
 
-# ------------------------------------------------------------------ BASELINE configurations
+# ------------------------------------------------------------------ the named configurations
 def _rmse(a, b):
     return float(np.sqrt(np.mean((a[..., :3].astype(np.float64) - b[..., :3].astype(np.float64)) ** 2)))
 
