@@ -295,6 +295,19 @@ int rt_trace_rays(RtContext *ctx, const float *origins, const float *directions,
 int rt_trace_rays_device(RtContext *ctx, const void *device_origins4, const void *device_dirs4,
                          uint32_t n, void *device_hits4);
 
+/* rt_trace_rays_device without any allocation.  No counterpart in the reference: it is for
+ * callers that cannot allocate device memory -- code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  The walker's scratch (ray cursor, overflow flag,
+ * the stack levels a lane spills) lives in a static device array of 20 MB that every GPU the
+ * library runs on holds until the process ends, instead of buffers of the context; the call
+ * makes no hipMalloc / hipFree, creates no events and keeps no timing.  Same inputs, outputs
+ * and results as rt_trace_rays_device, for at most RT_TRACE_STATIC_MAX_RAYS rays per call
+ * (more: RT_E_INVALID).  All calls on one GPU share that GPU's array: calls that overlap on a
+ * GPU (two contexts, two threads) race; one after the other is fine. */
+#define RT_TRACE_STATIC_MAX_RAYS (1u << 24)
+int rt_trace_rays_device_static(RtContext *ctx, const void *device_origins4, const void *device_dirs4,
+                                uint32_t n, void *device_hits4);
+
 /* Numeric self-check: evaluates one of the shared numeric rules of rt_math.h on
  * the device for n host inputs (which: 0 sin, 1 cos, 2 acos, 3 pow(x,y),
  * 4 sRGB->linear, 5 linear->sRGB, 6 float->uint as bits, 7 the Rand() stream of

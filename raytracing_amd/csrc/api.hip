@@ -135,6 +135,10 @@ int rt_create(int device_id, RtContext **out_ctx)
     (void)hipMemset(ctx->dStats, 0, 64 * sizeof(unsigned long long));
     (void)hipMemset(ctx->dErrorFlag, 0, 4);
     (void)hipMemset(ctx->dQCount, 0, RT_COUNTER_BLOCK_WORDS * 4);
+    if (rt_static_scratch_init(ctx) != RT_OK) {    // the address of this device's static scratch array (rt_trace_rays_device_static)
+        (void)rt_destroy(ctx);
+        return RT_E_DEVICE;
+    }
     *out_ctx = ctx;
     return RT_OK;
 }
@@ -501,6 +505,16 @@ int rt_trace_rays_device(RtContext *ctx, const void *device_origins4, const void
     (void)hipEventDestroy(e1);
     rt_timer_resolve(ctx);
     return check_error_flag(ctx);
+}
+
+int rt_trace_rays_device_static(RtContext *ctx, const void *device_origins4, const void *device_dirs4, uint32_t n, void *device_hits4)
+{
+    RT_ENTER(ctx);
+    if (!ctx->built) return rt_fail(ctx, RT_E_STATE, "rt_bvh_build has not been called");
+    if (n > RT_TRACE_STATIC_MAX_RAYS)
+        return rt_fail(ctx, RT_E_INVALID, "rt_trace_rays_device_static: %u rays exceed the maximum of %u per call", n, RT_TRACE_STATIC_MAX_RAYS);
+    if (n && (!device_origins4 || !device_dirs4 || !device_hits4)) return rt_fail(ctx, RT_E_INVALID, "null ray buffers");
+    return rt_trace_device_static_impl(ctx, (const float4 *)device_origins4, (const float4 *)device_dirs4, n, (RtHitRec *)device_hits4);
 }
 
 int rt_trace_rays(RtContext *ctx, const float *origins, const float *directions, uint32_t n, float *out_t, uint32_t *out_triangle,

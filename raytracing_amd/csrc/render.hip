@@ -1253,6 +1253,68 @@ int rt_trace_device_impl(RtContext *ctx, const float4 *o, const float4 *d, uint3
     return RT_OK;
 }
 
+// ---- first-hit queries that allocate nothing
+// The walker's scratch -- the ray cursor, the overflow flag and the per-lane spill levels of the stack -- in a
+// file-scope array instead of buffers the context allocates, for callers that may not allocate device memory
+// (code under HIP graph capture, tight serving loops).  Every GPU the library runs on holds one copy of the
+// array until the process ends; all calls on a GPU share it, so calls that overlap on one GPU race.
+//   words 0..31   the ray cursor's line          (cleared by every call)
+//   words 32..63  the overflow flag's line       (cleared by every call)
+//   from word 64  RT_STATIC_BLOCKS x TRV_THREADS lanes x (RT_STACK_DEPTH - TRV_STACK_LDS) stack levels (written before read)
+#define RT_STATIC_BLOCKS 1280u                                     // five resident blocks on each of 256 compute units
+#define RT_STATIC_HEAD_WORDS 64u
+#define RT_STATIC_SPILL_WORDS (RT_STATIC_BLOCKS * TRV_THREADS * (RT_STACK_DEPTH - TRV_STACK_LDS))
+static __device__ __align__(256) uint32_t scratch[RT_STATIC_HEAD_WORDS + RT_STATIC_SPILL_WORDS];   // 20 MB
+
+// In host code `scratch` is only a handle for the runtime; the memory of each GPU's copy is found once per
+// device, with that device current, and only that pointer is used from then on.
+#define RT_STATIC_MAX_DEVICES 64
+static std::mutex g_scratchMutex;
+static uint32_t *g_scratchPtr[RT_STATIC_MAX_DEVICES];
+
+int rt_static_scratch_init(RtContext *ctx)
+{
+    if (ctx->device < 0 || ctx->device >= RT_STATIC_MAX_DEVICES) return RT_OK;    // such a device gets no allocation-free entry point
+    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    if (g_scratchPtr[ctx->device]) return RT_OK;
+    uint32_t *ptr = nullptr;
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    RT_HIP(ctx, hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));
+    if (!ptr) return rt_fail(ctx, RT_E_DEVICE, "hipGetSymbolAddress gave no address for the static scratch array");
+    g_scratchPtr[ctx->device] = ptr;
+    return RT_OK;
+}
+
+int rt_trace_device_static_impl(RtContext *ctx, const float4 *o, const float4 *d, uint32_t n, RtHitRec *hits)
+{
+    uint32_t *ptr = nullptr;
+    if (ctx->device >= 0 && ctx->device < RT_STATIC_MAX_DEVICES) {
+        std::lock_guard<std::mutex> lock(g_scratchMutex);
+        ptr = g_scratchPtr[ctx->device];
+    }
+    if (!ptr) return rt_fail(ctx, RT_E_STATE, "no static scratch array on device %d", ctx->device);
+    if (n == 0) return RT_OK;
+    RtSceneView sv = rt_scene_view(ctx);
+    sv.stats = nullptr;
+    sv.errorFlag = ptr + 32;
+    sv.stackSpill = ptr + RT_STATIC_HEAD_WORDS;
+    RT_HIP(ctx, hipMemsetAsync(ptr, 0, RT_STATIC_HEAD_WORDS * sizeof(uint32_t), ctx->stream));
+    ArraySrc src;
+    src.org = o;
+    src.dir = d;
+    src.n = n;
+    src.hits = hits;
+    uint32_t blocks = (n + TRV_THREADS - 1) / TRV_THREADS;
+    if (blocks > RT_STATIC_BLOCKS) blocks = RT_STATIC_BLOCKS;      // the spill area holds that many blocks' lanes
+    hipLaunchKernelGGL((k_traverse<false, ArraySrc>), dim3(blocks), dim3(TRV_THREADS), 0, ctx->stream, sv, src, ptr);
+    RT_HIP(ctx, hipGetLastError());
+    uint32_t flag = 0;
+    RT_HIP(ctx, hipMemcpyAsync(&flag, ptr + 32, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (flag) return rt_fail(ctx, RT_E_OVERFLOW, "traversal stack overflow (depth > %d)", RT_STACK_DEPTH);
+    return RT_OK;
+}
+
 int rt_trace_primitives_impl(RtContext *ctx, const float4 *o, const float4 *d, uint32_t n, float *t, uint32_t *prim, float *normal3)
 {
     RtHitRec *hits = nullptr;

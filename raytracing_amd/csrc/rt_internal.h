@@ -277,6 +277,8 @@ int rt_shadowmap_impl(RtContext *ctx);
 int rt_accumulate_impl(RtContext *ctx, uint32_t samplePerPixel, int useShadowMap);
 int rt_render_frames_impl(RtContext *ctx, const float *seeds, uint32_t nFrames);
 int rt_trace_device_impl(RtContext *ctx, const float4 *o, const float4 *d, uint32_t n, RtHitRec *hits);
+int rt_static_scratch_init(RtContext *ctx);   // once per device, from rt_create
+int rt_trace_device_static_impl(RtContext *ctx, const float4 *o, const float4 *d, uint32_t n, RtHitRec *hits);
 int rt_expand_local_impl(RtContext *ctx, const float4 *local, float4 *full);
 int rt_trace_primitives_impl(RtContext *ctx, const float4 *o, const float4 *d, uint32_t n, float *t, uint32_t *prim, float *normal3);
 int rt_pack_rays_impl(RtContext *ctx, const float *o3, const float *d3, uint32_t n, float4 *o4, float4 *d4);

@@ -24,7 +24,7 @@ EXPORTS = [
     "rt_kernel_time", "rt_synchronize", "rt_version", "rt_debug_eval", "rt_set_option",
     "rt_image_upload", "rt_image_size", "rt_post_blit", "rt_post_color_correction", "rt_post_lut_upload",
     "rt_post_color_grading", "rt_post_bloom", "rt_save_rgb24", "rt_primitives_upload", "rt_trace_primitives",
-    "rt_readback_walk_tree",
+    "rt_readback_walk_tree", "rt_trace_rays_device_static",
 ]
 
 _lib = None
@@ -232,6 +232,11 @@ class RtCore:
     def trace_rays_device(self, origins4_ptr, dirs4_ptr, n, hits4_ptr):
         self._check(self.lib.rt_trace_rays_device(self.ctx, C.c_void_p(origins4_ptr), C.c_void_p(dirs4_ptr), C.c_uint32(n),
                                                   C.c_void_p(hits4_ptr)))
+
+    def trace_rays_device_static(self, origins4_ptr, dirs4_ptr, n, hits4_ptr):
+        """rt_trace_rays_device through the library's static scratch array: no allocation in the call."""
+        self._check(self.lib.rt_trace_rays_device_static(self.ctx, C.c_void_p(origins4_ptr), C.c_void_p(dirs4_ptr), C.c_uint32(n),
+                                                         C.c_void_p(hits4_ptr)))
 
     def debug_eval(self, which, x, y=None, n=None):
         x = np.ascontiguousarray(x, np.float32)
