@@ -6,8 +6,13 @@ mesh and HDRIs are absent from the reference checkout), 1920x1080, 64 samples
 per pixel.  One STEP = one finished 64-spp image = 64 x { CSMain dispatch,
 ShadowMap dispatch, accumulate } = 64 calls of the reference's CustomRender
 (Assets/Scripts/RayTracing/RayTracing.cs:118-164), followed by gathering the
-accumulated tiles on rank 0.  value = Mrays/s over the whole job, where one ray
-is one BVHRayTrace call actually executed (camera, bounce or shadow segment).
+accumulated tiles on rank 0.  value = Mrays/s over the whole job, counting RAYS
+ANSWERED: every BVHRayTrace call (camera, bounce or shadow segment) the reference
+makes for the same frames.  Some of them the library settles without a walk (the
+16 soft-shadow rays of a ShadowMap pixel none of whose rays can meet a shadow
+caster); "rays_walked" are the rays a traversal kernel actually took through the
+tree, and "value_rays_walked" is the same rate counted on those alone.  The CPU
+leg counts the same way (it walks every ray it answers).
 
 For N > 1 the fixed frame is cut into 64x64 tiles dealt round-robin to the ranks
 (strong scaling); the scene is broadcast once with RCCL before the timed region
@@ -31,6 +36,19 @@ from raytracing_amd import native, scenes, wire  # noqa: E402
 from raytracing_amd import dist as rtdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, spec
+SIMDS = 256 * 4         # compute units x SIMDs
+MAX_CLOCK_GHZ = 2.4     # a wave64 vector instruction occupies its SIMD for 4 clocks
+VALU_PEAK_GINST = SIMDS * MAX_CLOCK_GHZ / 4.0   # wave-instructions per ns over the chip = 614.4 G/s
+
+
+def source_id():
+    """Hash of the kernel sources: profiles/pmc_traffic.json records the one it was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "raytracing_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
 
 
 def make_scene(args):
@@ -81,16 +99,16 @@ def cpu_baseline(sc, args):
         _, cnt = orc.render(p, counters=True)
         rays += cnt["rays"]
         if use_shadow:
-            sm = orc.shadowmap(p)
-            # ShadowMap kernel: 1 primary ray per pixel + 16 shadow rays per pixel that hit something (alpha or shadow < 1 marks a hit)
-            hit = (sm[..., 3] > 0) | (sm[..., 0] < 1) | (sm[..., 1] < 1) | (sm[..., 2] < 1)
-            rays += w * h + 16 * int(hit.sum())
+            # the ShadowMap kernel as the reference runs it: 1 primary ray per pixel + 16 shadow rays per pixel whose
+            # primary ray hit something, every one of them walked
+            _, scnt = orc.shadowmap(p, counters=True)
+            rays += scnt["rays"]
         frames += 1
     dt = time.time() - t0
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": int(oracle_py.lib().orc_num_threads()), "kind": "port",
             "ms_per_frame_1spp_at_full_resolution": round(dt / frames * (args.width * args.height) / (w * h) * 1e3, 1),
             "sample": f"{sc.name} scene, {w}x{h} (1/16 of the pixels), {frames} frame(s) of 1 spp incl. ShadowMap pass, "
-                      f"{dt:.1f} s; shadow rays of matte-mask pixels whose 16 rays all miss are not counted"}
+                      f"{dt:.1f} s; every BVHRayTrace call counted (the checker walks each one)"}
 
 
 def main():
@@ -108,6 +126,7 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the per-frame drop-in leg")
     ap.add_argument("--plain-order", action="store_true", help="one launch after the other on one stream (for hardware-counter "
                                                                "passes, which see each kernel by itself)")
     args = ap.parse_args()
@@ -175,12 +194,14 @@ def main():
     step()
     st = core.stats()
     core.enable_counters(False)
-    counts = torch.tensor([st[k] for k in COUNT_KEYS], dtype=torch.int64, device=comm_device)
+    ALL_KEYS = COUNT_KEYS + ("raysWalked",)
+    counts = torch.tensor([st[k] for k in ALL_KEYS], dtype=torch.int64, device=comm_device)
     local_shadow = {k: int(st[sk]) for k, sk in zip(COUNT_KEYS, SHADOW_KEYS)}
     local_path = {k: int(st[k]) - local_shadow[k] for k in COUNT_KEYS}
     if world > 1:
         dist.all_reduce(counts)
-    total = {k: int(v) for k, v in zip(COUNT_KEYS, counts.tolist())}
+    total = {k: int(v) for k, v in zip(ALL_KEYS, counts.tolist())}
+    rays_answered, rays_walked = total["rays"], total["raysWalked"]
 
     for _ in range(args.warmup):
         step()
@@ -196,6 +217,28 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
+    # ---- the per-frame drop-in sequence (untimed by `value`): what RayTracing.CustomRender does once per
+    # OnRenderImage (RayTracing.cs:118-164) when the host keeps its own frame loop: UpdateParameters (new seed),
+    # Dispatch(CSMain), Dispatch(ShadowMap), Blit(addMaterial) -- one frame in flight, nothing shared between passes.
+    dropin_frames = 0 if args.no_dropin else min(args.spp, 16)
+    dropin_ms = None
+    if dropin_frames:
+        use_shadow = bool(params.flags & wire.FLAG_MATTE_MASK)
+        for timed in (False, True):
+            core.set_dirty()
+            core.synchronize()
+            t1 = time.perf_counter()
+            for k in range(dropin_frames):
+                params.seed = float(seeds[k])
+                core.set_params(params)
+                core.dispatch()
+                if use_shadow:
+                    core.dispatch_shadowmap()
+                core.accumulate(k, use_shadow)
+            core.synchronize()
+            if timed:
+                dropin_ms = (time.perf_counter() - t1) / dropin_frames * 1e3
+
     # ---- roofline pass (untimed by the wall clock): the same step with every launch bracketed by HIP events
     # on the library's stream.  With the events on, the library keeps its launches in the plain order (the
     # shadow rays are otherwise walked while the later bounces run, by two launches that share the chip with
@@ -209,51 +252,64 @@ def main():
     core.synchronize()
     core.enable_kernel_timing(False)
     if world > 1:
-        et = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
+        et = torch.tensor([elapsed, dropin_ms or 0.0], dtype=torch.float64, device=comm_device)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
-        elapsed = float(et.item())
+        elapsed = float(et[0].item())
+        dropin_ms = float(et[1].item()) or None
 
     workload_name = (f"{sc.name} scene (procedural stand-in), {args.width}x{args.height}, {args.spp} spp per step, "
                      f"{sc.n_triangles} triangles, MIS + DoF + ShadowMap pass")
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = total["rays"] * args.steps / elapsed / 1e6
+        value = rays_answered * args.steps / elapsed / 1e6
         # The traversal kernel has two instantiations in a step: k_traverse<QueueSrc> (camera and bounce
         # rays, timed as "k_extend") and k_traverse<ShadowSrc> (16 shadow rays per pixel, "k_shadow_rays").
         # The roofline is quoted for whichever took more device time; the other one is reported beside it.
-        # Byte counts are this rank's own counters (its launches moved its share of the rays).
+        # Both are bound by vector-instruction issue, not by HBM: the tree (tens of MB) is served by L2 and the
+        # Infinity Cache, the memory side moves a twentieth of the bytes the rays ask for.  So:
+        #   bound "valu": achieved = vector wave-instructions per launch / launch time, peak = 1024 SIMDs x 2.4 GHz / 4
+        #                 clocks per wave64 instruction; `useful` = frac x the share of lanes active in those instructions.
+        #   "hbm": the memory-side bytes of the same launch (FETCH_SIZE x 2 + WRITE_SIZE) / launch time against 8 TB/s.
+        # Instruction and byte counts per launch come from the committed rocprofv3 --pmc passes of this same command
+        # (profiles/pmc_traffic.json, which records the workload and the hash of the kernel sources it was measured
+        # on); the launch time is measured live, here, with HIP events on the library's stream.
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         measured = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        sid = source_id()
 
-        def roof(timer, kernel, nbytes):
+        def roof(timer, kernel, alg_bytes, units):
             ms, n = core.kernel_time(timer)
             if not n:
                 return None, 0.0
-            per_launch = nbytes * roof_steps / n
-            achieved = per_launch / (ms / n * 1e-3) / 1e9
+            dur = ms / n * 1e-3
             m = measured.get(kernel, {})
             same = m.get("workload") == workload_name and m.get("n_gpus") == world
-            traffic = m.get("hbm_bytes_per_launch") if same else None
-            counters = None
-            if same:   # from the committed rocprofv3 --pmc passes of this same command (profiles/)
-                counters = {k: m.get(k) for k in ("l2_hit_rate", "lane_utilisation", "waves_per_simd", "valu_busy")}
-                counters["hbm_gbps"] = round(traffic / (ms / n * 1e-3) / 1e9, 1)
-                counters["hbm_frac_of_peak"] = round(counters["hbm_gbps"] / HBM_PEAK_GBS, 4)
-            return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": traffic, "counters": counters,
-                    "kernel": kernel, "launches": int(n), "avg_launch_ms": round(ms / n, 4),
-                    "algorithmic_bytes_per_launch": int(per_launch),
-                    "note": "achieved = algorithmic bytes (every box, leaf and triangle record a ray needs, counted by the "
-                            "instrumented kernel) / launch time; traffic = memory-side bytes per launch (FETCH_SIZE x 2 + "
-                            "WRITE_SIZE) from the committed PMC passes. The tree is re-read from L2 / Infinity Cache, hence "
-                            "traffic << algorithmic bytes and frac is not capped at 1; the kernel's binding resource is "
-                            "vector-instruction issue (counters.valu_busy x counters.lane_utilisation). avg_launch_ms comes "
-                            "from a pass after the timed steps with HIP events round every launch; the library then keeps "
-                            "the plain launch order, so it is the kernel by itself"}, ms
+            out = {"bound": "valu", "achieved": None, "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instructions/s", "frac": None,
+                   "useful": None, "traffic": None, "kernel": kernel, "launches": int(n), "avg_launch_ms": round(ms / n, 4),
+                   "rays_per_launch": int(units * roof_steps / n)}
+            per_launch = alg_bytes * roof_steps / n
+            out["algorithmic_bytes_per_launch"] = int(per_launch)
+            out["algorithmic_gbps_served_by_caches"] = round(per_launch / dur / 1e9, 1)
+            if same:
+                valu = m["valu_instructions_per_launch"]
+                out["achieved"] = round(valu / dur / 1e9, 2)
+                out["frac"] = round(valu / dur / 1e9 / VALU_PEAK_GINST, 4)
+                out["useful"] = round(out["frac"] * m["lane_utilisation"], 4)
+                out["traffic"] = m["hbm_bytes_per_launch"]
+                gbps = m["hbm_bytes_per_launch"] / dur / 1e9
+                out["hbm"] = {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(gbps / HBM_PEAK_GBS, 4), "traffic_over_algorithmic": round(m["hbm_bytes_per_launch"] / per_launch, 4)}
+                out["counters"] = {k: m.get(k) for k in ("l2_hit_rate", "lane_utilisation", "waves_per_simd", "valu_busy",
+                                                         "valu_instructions_per_launch", "kernel_clocks_per_launch")}
+                out["pmc_sources_match"] = m.get("source_id") == sid
+            out["note"] = ("frac = vector wave-instructions x 4 clocks / (1024 SIMDs x launch time x 2.4 GHz): the share of the chip's "
+                           "vector issue slots the launch used; useful = frac x lane utilisation. Instruction and memory-side byte "
+                           "counts per launch: committed rocprofv3 --pmc passes of this command (profiles/), launch time: HIP events "
+                           "here, plain launch order. The HBM figure is an upper bound (FETCH_SIZE also counts Infinity-Cache hits)")
+            return out, ms
 
-        r_path, ms_path = roof("k_extend", "k_traverse<QueueSrc>", path_ray_bytes(local_path))
-        r_shadow, ms_shadow = roof("k_shadow_rays", "k_traverse<ShadowSrc>", shadow_ray_bytes(local_shadow))
+        r_path, ms_path = roof("k_extend", "k_traverse<QueueSrc>", path_ray_bytes(local_path), local_path["rays"])
+        r_shadow, ms_shadow = roof("k_shadow_rays", "k_traverse<ShadowSrc>", shadow_ray_bytes(local_shadow), int(st["shadowRaysWalked"]))
         roofline, other = (r_shadow, r_path) if ms_shadow >= ms_path else (r_path, r_shadow)
         out = {
             "metric": "Mrays/s", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
@@ -261,9 +317,16 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_name,
                        "parallelism": f"image tiles 64x64 round-robin over {world} GPU(s)"},
+            "value_counts": "rays_answered (every BVHRayTrace call the reference makes for these frames)",
+            "rays_answered_per_step": rays_answered, "rays_walked_per_step": rays_walked,
+            "value_rays_walked": round(rays_walked * args.steps / elapsed / 1e6, 3),
             "ms_per_frame_1spp": round(ms_per_step / args.spp, 4),
             "ms_per_image": round(ms_per_step, 3),
-            "rays_per_step": total["rays"], "paths_per_step": args.width * args.height * args.spp,
+            "per_frame_dropin": None if dropin_ms is None else {
+                "ms_per_frame_1spp": round(dropin_ms, 4), "frames": dropin_frames,
+                "sequence": "rt_set_params(seed) + rt_dispatch + rt_dispatch_shadowmap + rt_accumulate per frame (RayTracing.cs:118-164), "
+                            "one frame in flight"},
+            "paths_per_step": args.width * args.height * args.spp,
             "bvh_build_ms": round(build_ms, 3),
             "bvh_build_mtris_per_s": round(sc.n_triangles / max(build_ms, 1e-6) / 1e3, 2),
             "traversal_counts_per_step": total,

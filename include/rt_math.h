@@ -28,7 +28,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define RT_HD __host__ __device__ inline
 #else
 #define RT_HD inline

@@ -153,7 +153,9 @@ typedef struct RtContext RtContext;
 
 /* Work counters of the BVH traversal since the last rt_reset_stats. */
 typedef struct RtStats {
-    uint64_t rays;            /* BVHRayTrace calls */
+    uint64_t rays;            /* BVHRayTrace calls ANSWERED: every call the reference would make for the same frames,
+                                 including the 16 soft-shadow rays of ShadowMap pixels that the library settles without a
+                                 walk (no ray of the pixel can meet a shadow caster); see raysWalked */
     uint64_t internalVisits;  /* internal-node boxes tested (n_I)  */
     uint64_t leafVisits;      /* leaf triangle boxes tested (n_L)  */
     uint64_t triTests;        /* triangles that passed their box (n_T) */
@@ -164,6 +166,9 @@ typedef struct RtStats {
     /* the part of rays / internalVisits / leafVisits / triTests / hits due to the 16 soft-shadow
      * rays per pixel of the ShadowMap pass (Shadow.cginc:95-111) */
     uint64_t shadowRays, shadowInternalVisits, shadowLeafVisits, shadowTriTests, shadowHits;
+    /* the rays that a traversal kernel actually took through the tree (rays - raysWalked were answered without a walk);
+     * a ray that the first-hit rule ends early counts as walked */
+    uint64_t raysWalked, shadowRaysWalked;
 } RtStats;
 
 /* ---------------------------------------------------------------- lifetime */

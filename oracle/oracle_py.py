@@ -141,8 +141,12 @@ class Oracle:
             return img, dict(zip(("rays", "internalVisits", "leafVisits", "triTests", "hits"), map(int, cnt)))
         return img
 
-    def shadowmap(self, params):
+    def shadowmap(self, params, counters=False):
         img = np.zeros((params.height, params.width, 4), np.float32)
+        if counters:
+            cnt = np.zeros(5, np.uint64)
+            lib().orc_shadowmap_counted(self.h, C.byref(params), _p(img), _p(cnt))
+            return img, dict(zip(("rays", "internalVisits", "leafVisits", "triTests", "hits"), map(int, cnt)))
         lib().orc_shadowmap(self.h, C.byref(params), _p(img))
         return img
 

@@ -1752,6 +1752,29 @@ void orc_shadowmap(void *h, const RtParams *P, float *dst)
             ShadowMapKernel(s, *P, (uint32_t)x, (uint32_t)y, dst + ((size_t)y * P->width + x) * 4, nullptr);
 }
 
+// The same kernel with the traversal work counted: 1 primary ray per pixel and 16 soft-shadow rays per pixel
+// whose primary ray hit (rays, internalVisits, leafVisits, triTests, hits).
+void orc_shadowmap_counted(void *h, const RtParams *P, float *dst, uint64_t *counters)
+{
+    const Scene &s = *(Scene *)h;
+    TraceCounters total = {0, 0, 0, 0, 0};
+#pragma omp parallel
+    {
+        TraceCounters c = {0, 0, 0, 0, 0};
+#pragma omp for schedule(dynamic, 1)
+        for (int y = 0; y < P->height; ++y)
+            for (int x = 0; x < P->width; ++x)
+                ShadowMapKernel(s, *P, (uint32_t)x, (uint32_t)y, dst + ((size_t)y * P->width + x) * 4, &c);
+#pragma omp critical
+        {
+            total.rays += c.rays; total.internalVisits += c.internalVisits; total.leafVisits += c.leafVisits;
+            total.triTests += c.triTests; total.hits += c.hits;
+        }
+    }
+    counters[0] = total.rays; counters[1] = total.internalVisits; counters[2] = total.leafVisits;
+    counters[3] = total.triTests; counters[4] = total.hits;
+}
+
 // AddShader.shader:12,47-79 with Blend SrcAlpha OneMinusSrcAlpha on a float target.
 void orc_accumulate(float *converged, const float *rt, const float *shadowMap, uint32_t samplePrePixel,
                     uint64_t nPixels, int pass)

@@ -332,6 +332,9 @@ int rt_set_params(RtContext *ctx, const RtParams *p)
     const uint32_t T = (uint32_t)tm.tilesX * (uint32_t)tm.tilesY;
     tm.nLocalTiles = T > (uint32_t)q.tileRank ? (T - (uint32_t)q.tileRank + (uint32_t)q.tileCount - 1) / (uint32_t)q.tileCount : 0;
     tm.nSlots = tm.nLocalTiles * (uint32_t)(q.tileSize * q.tileSize);
+    // ray indices are 32-bit: 16 shadow rays per path slot of one frame must fit
+    if ((uint64_t)tm.nLocalTiles * (uint64_t)(q.tileSize * q.tileSize) * 16ull >= (1ull << 32))
+        return rt_fail(ctx, RT_E_INVALID, "%d x %d pixels are too many for one context: split the frame into more tiles (tileCount)", q.width, q.height);
     const bool geometryChanged = !ctx->paramsSet || memcmp(&tm, &ctx->tile, sizeof tm) != 0;
     ctx->params = q;
     ctx->tile = tm;
@@ -632,13 +635,15 @@ int rt_get_stats(RtContext *ctx, RtStats *out)
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     unsigned long long h[40];   // [0..4] all launches but the shadow rays, [32..36] shadow-ray launches
     RT_HIP(ctx, hipMemcpy(h, ctx->dStats, sizeof h, hipMemcpyDeviceToHost));
-    out->rays = h[0] + h[32];
+    out->rays = h[0] + h[32] + h[37];       // [37]: shadow rays of pixels that got none (k_sm_setup)
+    out->raysWalked = h[0] + h[32];
+    out->shadowRaysWalked = h[32];
     out->internalVisits = h[1] + h[33];
     out->leafVisits = h[2] + h[34];
     out->triTests = h[3] + h[35];
     out->hits = h[4] + h[36];
     out->paths = h[5];
-    out->shadowRays = h[32];
+    out->shadowRays = h[32] + h[37];
     out->shadowInternalVisits = h[33];
     out->shadowLeafVisits = h[34];
     out->shadowTriTests = h[35];
@@ -647,6 +652,9 @@ int rt_get_stats(RtContext *ctx, RtStats *out)
     out->renderMs = ctx->renderMs;
     return RT_OK;
 }
+
+/* The frames-in-flight rule by itself, for host-side checks (no GPU needed).  Not part of rtcore.h. */
+uint32_t rt_debug_batch_frames(uint32_t n_slots, uint32_t option, uint32_t wanted) { return rt_batch_frames_rule(n_slots, option, wanted); }
 
 /* Phase profile of the one-ray-per-lane walker (library built with -DTRV_PROFILE): 4 clock sums
  * (refill, node, triangle, retire) and 6 counts, summed over waves.  Not part of rtcore.h. */

@@ -551,7 +551,7 @@ __global__ __launch_bounds__(Q_THREADS) void k_sm_setup(RtSceneView sv, RtTileMa
         }
     }
     stage[it * Q_THREADS + threadIdx.x] = shaded ? slot : RT_INVALID;
-    if (shadowRayCounter) {     // counters on: the 16 rays of a pixel that got none are rays answered all the same
+    if (shadowRayCounter) {     // counters on: the 16 rays of a pixel that got none are rays answered (not walked) all the same
         const unsigned long long m = __ballot(skipped);
         if ((threadIdx.x & 63u) == 0 && m) atomicAdd(shadowRayCounter, 16ull * (unsigned long long)__popcll(m));
     }
@@ -684,7 +684,8 @@ RtSceneView rt_scene_view(RtContext *ctx)
     sv.cube = ctx->dCube;
     sv.cubeSize = ctx->cubeSize;
     sv.stats = ctx->dStats;
-    sv.stackSpill = ctx->dStackSpill;
+    // walker launches that may be on the chip together spill into different areas
+    sv.stackSpill = ctx->dStackSpill + (size_t)ctx->spillArea * ctx->numCU * RT_SPILL_WORDS_PER_CU;
     sv.errorFlag = ctx->dErrorFlag;
     return sv;
 }
@@ -772,17 +773,24 @@ int rt_alloc_render(RtContext *ctx)
     return alloc_batch(ctx, 1);
 }
 
-uint32_t rt_batch_frames(RtContext *ctx, uint32_t wanted)
+// Frames rt_render_frames keeps in flight for a tile share of nSlots path slots: `option` = RT_OPT_BATCH_FRAMES
+// (0: by path count), `wanted` = frames asked for.
+uint32_t rt_batch_frames_rule(uint32_t nSlots, uint32_t option, uint32_t wanted)
 {
     // As many frames in flight as 128 M paths allow, 64 at most: 64 frames of a whole 1080p image, 16 of a
     // 4K image.  The bounce launches of a frame are latency-bound (each lasts as long as its longest ray,
     // and deep bounces hold few rays), so the more frames share them the better: 8 / 16 / 32 / 64 frames in
-    // flight gave 5.1 / 4.4 / 4.0 / 3.8 ms per 1080p frame.  optBatchFrames = 0 means this rule.
-    const uint32_t n = ctx->tile.nSlots ? ctx->tile.nSlots : 1;
-    uint32_t cap = ctx->optBatchFrames ? ctx->optBatchFrames : RT_BATCH_PATH_SLOTS / n;
+    // flight gave 5.1 / 4.4 / 4.0 / 3.8 ms per 1080p frame.
+    // An explicit RT_OPT_BATCH_FRAMES is held to the same path count: ray indices (16 shadow rays per path)
+    // and ray cursors are 32-bit, so nSlots * frames * 16 must stay below 2^32.
+    const uint32_t n = nSlots ? nSlots : 1;
+    const uint32_t byPaths = RT_BATCH_PATH_SLOTS / n;
+    uint32_t cap = option && option < byPaths ? option : byPaths;
     cap = cap < 1u ? 1u : (cap > RT_MAX_BATCH ? RT_MAX_BATCH : cap);
     return wanted < cap ? (wanted ? wanted : 1u) : cap;
 }
+
+uint32_t rt_batch_frames(RtContext *ctx, uint32_t wanted) { return rt_batch_frames_rule(ctx->tile.nSlots, ctx->optBatchFrames, wanted); }
 
 // Persistent launch: enough resident waves to fill the chip; every wave pulls rays from the
 // shared cursor until none are left.
@@ -835,7 +843,7 @@ static void launch_sm_setup(RtContext *ctx, const RtSceneView &sv, uint32_t tota
     rt_timer_begin(ctx, "k_sm_setup");
     hipLaunchKernelGGL(k_sm_setup, dim3((total + Q_TILE - 1) / Q_TILE), dim3(Q_THREADS), 0, ctx->stream, sv, ctx->tile, ctx->params, queue, qcount,
                        ctx->dPo, ctx->dPd, ctx->dRng, ctx->dHit, ctx->dSmRec, ctx->dShadowMap, ctx->dSmQueue, ctx->dQCount + CNT_SMQ,
-                       shadow_frame(ctx), ctx->optCasterBox ? 1 : 0, ctx->countersOn ? ctx->dStats + 32 : nullptr);
+                       shadow_frame(ctx), ctx->optCasterBox ? 1 : 0, ctx->countersOn ? ctx->dStats + 37 : nullptr);
     rt_timer_end(ctx);
 }
 
@@ -1167,6 +1175,7 @@ struct RtLaneScope {
         c->dQueue[0] += off; c->dQueue[1] += off; c->dSmQueue += off; c->dSmRec += 2 * off; c->dSmFlags += 16 * off;
         c->dSeeds += firstFrame;
         c->dQCount = counters;
+        c->spillArea = 1;        // the overlapped shadow launch, the other user of area 1, is off with two streams
     }
     ~RtLaneScope()
     {
@@ -1174,6 +1183,7 @@ struct RtLaneScope {
         c->stream = stream;
         c->dRt = rt; c->dShadowMap = sm; c->dPo = po; c->dPd = pd; c->dPe = pe; c->dSmRec = smRec; c->dRng = rng; c->dHit = hit;
         c->dQueue[0] = q0; c->dQueue[1] = q1; c->dSmQueue = smq; c->dQCount = cnt; c->dSmFlags = smFlags; c->dSeeds = seeds;
+        c->spillArea = 0;
     }
 };
 

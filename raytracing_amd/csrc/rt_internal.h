@@ -225,6 +225,7 @@ struct RtContext {
 
     // stats / timing
     uint32_t *dStackSpill = nullptr;     // RT_SPILL_AREAS x numCU x RT_SPILL_WORDS_PER_CU words
+    uint32_t spillArea = 0;              // the area rt_scene_view hands out (1 while the second stream's launches are made)
     unsigned long long *dStats = nullptr; // 64 x u64: counters [0..4] / [32..36] (shadow rays), walker profile [16..25] / [48..57]
     uint32_t *dErrorFlag = nullptr;
     bool countersOn = false;
@@ -271,6 +272,7 @@ void rt_free_build(RtContext *ctx);
 // render.hip
 RtSceneView rt_scene_view(RtContext *ctx);
 int rt_alloc_render(RtContext *ctx);
+uint32_t rt_batch_frames_rule(uint32_t nSlots, uint32_t option, uint32_t wanted);
 void rt_free_render(RtContext *ctx);
 int rt_dispatch_impl(RtContext *ctx);
 int rt_shadowmap_impl(RtContext *ctx);

@@ -84,7 +84,8 @@ class RtStats(C.Structure):
                 ("triTests", C.c_uint64), ("hits", C.c_uint64), ("paths", C.c_uint64),
                 ("buildMs", C.c_double), ("renderMs", C.c_double),
                 ("shadowRays", C.c_uint64), ("shadowInternalVisits", C.c_uint64), ("shadowLeafVisits", C.c_uint64),
-                ("shadowTriTests", C.c_uint64), ("shadowHits", C.c_uint64)]
+                ("shadowTriTests", C.c_uint64), ("shadowHits", C.c_uint64),
+                ("raysWalked", C.c_uint64), ("shadowRaysWalked", C.c_uint64)]
 
 # rt_set_option
 OPT_PACKET_SHADOW, OPT_PACKET_PRIMARY, OPT_PACKET_TRACE, OPT_BATCH_FRAMES, OPT_MATERIAL_SORT, OPT_TWO_STREAMS = 0, 1, 2, 3, 4, 5

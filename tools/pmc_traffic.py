@@ -9,6 +9,10 @@ Usage: pmc_traffic.py <pmc_summary.json> <bench_line.json>"""
 import json
 import sys
 
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_id  # noqa: E402
+
 summary = json.load(open(sys.argv[1]))
 bench = json.load(open(sys.argv[2]))
 out = {}
@@ -41,7 +45,7 @@ for kname, v in summary.items():
         **acct,
         "hbm_bytes_per_launch": int((fetch + write) / n), "fetch_bytes_per_launch": int(fetch / n),
         "write_bytes_per_launch": int(write / n), "launches": n,
-        "workload": bench["config"]["workload"], "n_gpus": bench["n_gpus"],
+        "workload": bench["config"]["workload"], "n_gpus": bench["n_gpus"], "source_id": source_id(),
         "l2_hit_rate": round(v["TCC_HIT_sum"] / max(v["TCC_HIT_sum"] + v.get("TCC_MISS_sum", 0.0), 1.0), 4) if "TCC_HIT_sum" in v else None,
     }
 print(json.dumps(out, indent=1))

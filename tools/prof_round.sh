@@ -4,8 +4,8 @@
 # Usage: tools/prof_round.sh <out_dir>      (run from the repository root on the GPU box)
 set -u
 OUT=${1:-gpurun_out/prof}
-BENCH="--steps 1 --warmup 1 --no-cpu-baseline"
-PMCB="--steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing --plain-order"
+BENCH="--steps 1 --warmup 1 --no-cpu-baseline --no-dropin"
+PMCB="--steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing --plain-order --no-dropin"
 export TMPDIR=/tmp
 mkdir -p "$OUT"
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t -- python3 bench.py $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
