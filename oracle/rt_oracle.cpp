@@ -26,7 +26,7 @@
 
 #include "../include/rtcore.h"
 #include "../include/rt_math.h"
-#include "../include/rt_q16.h"
+#include "../include/rt_qh.h"
 #include "../include/rt_finekey.h"
 #include "../include/rt_rotate.h"
 
@@ -100,11 +100,11 @@ struct Scene {
     // The library's own traversal structures, rebuilt here so that its work counters can be checked:
     // a second tree over the same triangle boxes, made by the same steps from the keys of
     // include/rt_finekey.h (only N, triAABB and the build products of `walk` are filled), its child
-    // boxes on the 16-bit grid of include/rt_q16.h, and every triangle's place in the reference's
+    // boxes on the half-float grid of include/rt_qh.h, and every triangle's place in the reference's
     // visiting order (decides between equally distant triangles when the walk order differs).
     std::shared_ptr<Scene> walk;
     RtQGrid grid;
-    std::vector<uint32_t> qboxes;      // 6 words per internal node of `walk`: left box, right box
+    std::vector<uint32_t> qboxes;      // 6 words per internal node of `walk`: left box x, y, z, right box x, y, z (low | high << 16)
     std::vector<uint32_t> visitRank;   // per original triangle
     bool gridOk = true;
 };
@@ -360,7 +360,7 @@ void BVHConstructor(Scene &s)
 void RotateWalkTree(Scene &w);
 
 // The library's traversal boxes: every child box of the tree rounded outward onto
-// the 16-bit grid of the root box (include/rt_q16.h), 3 words per box.
+// the half-float grid of the root box (include/rt_qh.h), 3 words per box.
 // The tree the library's rays walk (no reference counterpart): the reference's own steps on finer keys.
 void BuildWalkTree(Scene &s)
 {
@@ -492,26 +492,15 @@ void BuildGridBoxes(Scene &ref)
     ref.qboxes.clear();
     ref.gridOk = true;
     if (ref.N < 2) return;
-    ref.grid = rt_q16_grid(ref.bvhData[0].min, ref.bvhData[0].max);
+    ref.grid = rt_qh_grid(ref.bvhData[0].min, ref.bvhData[0].max);
     ref.qboxes.resize((size_t)(ref.N - 1) * 6);
     const Scene &s = *ref.walk;
-    Scene &out = ref;
     for (uint32_t i = 0; i + 1 < s.N; ++i) {
         const RtInternalNode &n = s.inodes[i];
         const uint32_t child[2] = {n.leftNode, n.rightNode}, type[2] = {n.leftNodeType, n.rightNodeType};
         for (int c = 0; c < 2; ++c) {
             const RtAABB &b = type[c] == RT_INTERNAL_NODE ? s.bvhData[child[c]] : s.triAABB[s.sortedIdx[s.leaves[child[c]].index]];
-            uint32_t lo[3], hi[3];
-            for (int a = 0; a < 3; ++a) {
-                lo[a] = rt_q16_floor(out.grid.org[a], out.grid.step[a], b.min[a]);
-                hi[a] = rt_q16_ceil(out.grid.org[a], out.grid.step[a], b.max[a]);
-                if (rt_q16_plane(out.grid.org[a], out.grid.step[a], lo[a]) > b.min[a] || hi[a] > RT_Q16_MAX) out.gridOk = false;
-                if (hi[a] > RT_Q16_MAX) hi[a] = RT_Q16_MAX;
-            }
-            uint32_t *w = &out.qboxes[(size_t)i * 6 + c * 3];
-            w[0] = lo[0] | (lo[1] << 16);
-            w[1] = lo[2] | (hi[0] << 16);
-            w[2] = hi[1] | (hi[2] << 16);
+            if (!rt_qh_box(ref.grid, b.min, b.max, &ref.qboxes[(size_t)i * 6 + c * 3])) ref.gridOk = false;
         }
     }
 }
@@ -658,7 +647,7 @@ void IntersectTriangle(const Scene &s, const Ray &ray, RayHit &hit, TraceCounter
 // Restates the library's one-ray-per-lane walker on the CPU so that its work
 // counters can be compared exactly and its claim "same hit as the reference's
 // walk" can be checked on the CPU as well: child boxes rounded outward onto the
-// 16-bit grid of the root box and tested with rt_slab_maybe; the triangle's own
+// half-float grid of the root box and tested with rt_slab_maybe; the triangle's own
 // box exact, with the reference's test; rays with a zero / non-finite component
 // use the exact boxes and the reference's test everywhere.
 const RtAABB &ChildBox(const Scene &s, uint32_t node, uint32_t type)
@@ -671,11 +660,12 @@ void IntersectTriangleGrid(const Scene &ref, const Ray &ray, RayHit &hit, TraceC
     if (ref.N == 0) return;
     if (cnt) cnt->internalVisits++;
     if (ref.N < 2 || !RayBoxIntersection(ref.bvhData[0], ray)) return;
-    // a ray with a zero / non-finite direction component walks the reference's tree with the reference's test
-    const bool odd = rt_ray_needs_exact_walk(ray.origin, ray.direction);
-    const Scene &s = odd ? ref : *ref.walk;
+    // a ray with a zero / non-finite direction component (or slab constants out of range) walks the reference's
+    // tree with the reference's test
     const f3 r = rt_mk3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
     const RtRaySlab slab = rt_ray_slab(ref.grid, ray.origin, r);
+    const bool odd = rt_ray_needs_exact_walk(ray.origin, ray.direction) || !rt_slab_finite(slab);
+    const Scene &s = odd ? ref : *ref.walk;
     uint32_t stack[64];
     uint32_t sp = 0;
     stack[sp++] = 0;

@@ -11,6 +11,7 @@
 //   Assets/Shaders/BVH/BVH.compute:164-211               (k_fit, level-synchronous, no atomics)
 #include "rt_internal.h"
 #include "../../include/rt_finekey.h"
+#include "../../include/rt_qh.h"
 #include "../../include/rt_rotate.h"
 
 #define WAVE 64
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256) void k_tree(const uint32_t *__restrict__ codes
 __global__ __launch_bounds__(256) void k_fit(uint32_t n, const uint32_t *__restrict__ list, uint32_t iter, const uint32_t *__restrict__ left,
                                               const uint32_t *__restrict__ right, const uint32_t *__restrict__ sortedIdx,
                                               const float4 *__restrict__ triAABB, float4 *bvhData, uint32_t *done,
-                                              float4 *__restrict__ nodes)
+                                              float4 *__restrict__ nodes, const uint32_t *__restrict__ parent)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -357,10 +358,12 @@ __global__ __launch_bounds__(256) void k_fit(uint32_t n, const uint32_t *__restr
     else       { rmn = bvhData[ri * 2]; rmx = bvhData[ri * 2 + 1]; }
     bvhData[i * 2 + 0] = make_float4(rt_min(lmn.x, rmn.x), rt_min(lmn.y, rmn.y), rt_min(lmn.z, rmn.z), 0.0f);
     bvhData[i * 2 + 1] = make_float4(rt_max(lmx.x, rmx.x), rt_max(lmx.y, rmx.y), rt_max(lmx.z, rmx.z), 0.0f);
-    nodes[i * 4 + 0] = make_float4(lmn.x, lmn.y, lmn.z, lmx.x);
-    nodes[i * 4 + 1] = make_float4(lmx.y, lmx.z, rmn.x, rmn.y);
-    nodes[i * 4 + 2] = make_float4(rmn.z, rmx.x, rmx.y, rmx.z);
-    nodes[i * 4 + 3] = make_float4(__uint_as_float(l), __uint_as_float(r), 0.0f, 0.0f);
+    if (nodes) {               // the exact 64-byte node: both child boxes, the links, the parent (for the stackless exact walk)
+        nodes[i * 4 + 0] = make_float4(lmn.x, lmn.y, lmn.z, lmx.x);
+        nodes[i * 4 + 1] = make_float4(lmx.y, lmx.z, rmn.x, rmn.y);
+        nodes[i * 4 + 2] = make_float4(rmn.z, rmx.x, rmx.y, rmx.z);
+        nodes[i * 4 + 3] = make_float4(__uint_as_float(l), __uint_as_float(r), __uint_as_float(parent[i]), 0.0f);
+    }
     done[i] = iter;
 }
 
@@ -495,10 +498,12 @@ __global__ __launch_bounds__(256) void k_rotate(uint32_t n, const uint32_t *__re
     done[i] = iter;
 }
 
-// The exact 64-byte nodes (both child boxes + links) of a tree whose links and boxes are final.
-__global__ __launch_bounds__(256) void k_emit_nodes(uint32_t N, const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
-                                                     const uint32_t *__restrict__ sortedIdx, const float4 *__restrict__ triAABB,
-                                                     const float4 *__restrict__ bvhData, float4 *__restrict__ nodes)
+// ------------------------------------------------------------------ half-float traversal nodes
+// The 32-byte node of a tree whose links and boxes are final: both child boxes rounded outward onto the
+// half-float planes of the root-box grid (rt_qh.h).  A plane the grid cannot cover raises the error flag.
+__global__ __launch_bounds__(256) void k_emit_qnodes(uint32_t N, RtQGrid g, const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
+                                                      const uint32_t *__restrict__ sortedIdx, const float4 *__restrict__ triAABB,
+                                                      const float4 *__restrict__ bvhData, uint4 *__restrict__ qnodes, uint32_t *__restrict__ errorFlag)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N - 1) return;
@@ -506,43 +511,12 @@ __global__ __launch_bounds__(256) void k_emit_nodes(uint32_t N, const uint32_t *
     float a[6], b[6];
     load_box(l, sortedIdx, triAABB, bvhData, a);
     load_box(r, sortedIdx, triAABB, bvhData, b);
-    nodes[i * 4 + 0] = make_float4(a[0], a[1], a[2], a[3]);
-    nodes[i * 4 + 1] = make_float4(a[4], a[5], b[0], b[1]);
-    nodes[i * 4 + 2] = make_float4(b[2], b[3], b[4], b[5]);
-    nodes[i * 4 + 3] = make_float4(__uint_as_float(l), __uint_as_float(r), 0.0f, 0.0f);
-}
-
-// ------------------------------------------------------------------ 16-bit traversal nodes
-// Rounds every child box of the finished tree outward onto the root-box grid
-// (rt_q16.h).  A plane the grid cannot cover raises the error flag.
-__device__ inline bool quantise_box(const RtQGrid &g, const float mn[3], const float mx[3], uint32_t out[3])
-{
-    uint32_t lo[3], hi[3];
-    bool ok = true;
-    for (int a = 0; a < 3; ++a) {
-        lo[a] = rt_q16_floor(g.org[a], g.step[a], mn[a]);
-        hi[a] = rt_q16_ceil(g.org[a], g.step[a], mx[a]);
-        ok = ok && rt_q16_plane(g.org[a], g.step[a], lo[a]) <= mn[a] && hi[a] <= RT_Q16_MAX;
-        if (hi[a] > RT_Q16_MAX) hi[a] = RT_Q16_MAX;
-    }
-    out[0] = lo[0] | (lo[1] << 16);
-    out[1] = lo[2] | (hi[0] << 16);
-    out[2] = hi[1] | (hi[2] << 16);
-    return ok;
-}
-
-__global__ __launch_bounds__(256) void k_quantise(uint32_t NI, RtQGrid g, const RtNode64 *__restrict__ nodes,
-                                                   uint4 *__restrict__ qnodes, uint32_t *__restrict__ errorFlag)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= NI) return;
-    const RtNode64 n = nodes[i];
-    uint32_t l[3], r[3];
-    const bool okL = quantise_box(g, n.lmin, n.lmax, l);
-    const bool okR = quantise_box(g, n.rmin, n.rmax, r);
+    uint32_t wl[3], wr[3];
+    const bool okL = rt_qh_box(g, a, a + 3, wl);
+    const bool okR = rt_qh_box(g, b, b + 3, wr);
     if (!okL || !okR) *errorFlag = 2u;
-    qnodes[i * 2 + 0] = make_uint4(l[0], l[1], l[2], r[0]);
-    qnodes[i * 2 + 1] = make_uint4(r[1], r[2], n.left, n.right);
+    qnodes[i * 2 + 0] = make_uint4(wl[0], wl[1], wl[2], wr[0]);
+    qnodes[i * 2 + 1] = make_uint4(wr[1], wr[2], l, r);
 }
 
 // ------------------------------------------------------------------ leaf packing
@@ -762,7 +736,7 @@ static int build_tree_from_keys(RtContext *ctx, BuildScratch &sc, uint32_t N, ui
     return run_levels(ctx, sc, NI, "BVH fit", [&](uint32_t n, const uint32_t *list, uint32_t iter) {
         rt_timer_begin(ctx, "k_fit");
         hipLaunchKernelGGL(k_fit, dim3((n + 255) / 256), blk, 0, st, n, list, iter, left, right, sortedIdx, (const float4 *)ctx->dTriAABB,
-                           (float4 *)bvhData, sc.done, (float4 *)nodes);
+                           (float4 *)bvhData, sc.done, (float4 *)nodes, parent);
         rt_timer_end(ctx);
     });
 }
@@ -785,7 +759,6 @@ int rt_build_impl(RtContext *ctx)
     uint32_t *wKeys = nullptr, *wCodes = nullptr, *wSortedIdx = nullptr, *wLeft = nullptr, *wRight = nullptr, *wParent = nullptr,
              *wLeafParent = nullptr, *refSize = nullptr, *walkLeafOfTri = nullptr;
     RtAABB *wBvhData = nullptr;
-    RtNode64 *wNodes = nullptr;
 
     RT_HIP(ctx, dalloc(&ctx->dTriAABB, (size_t)N));
     RT_HIP(ctx, dalloc(&ctx->dMortonUnsorted, (size_t)N));
@@ -820,7 +793,6 @@ int rt_build_impl(RtContext *ctx)
     RT_HIP(ctx, dalloc(&refSize, (size_t)NI));
     RT_HIP(ctx, dalloc(&walkLeafOfTri, (size_t)N));
     RT_HIP(ctx, dalloc(&wBvhData, (size_t)NI));
-    RT_HIP(ctx, dalloc(&wNodes, (size_t)NI));
 
     hipStream_t st = ctx->stream;
     hipEvent_t e0, e1;
@@ -846,14 +818,14 @@ int rt_build_impl(RtContext *ctx)
     if (N >= 2) {
         RT_HIP(ctx, hipMemcpyAsync(&ctx->rootBox, ctx->dBvhData, sizeof(RtAABB), hipMemcpyDeviceToHost, st));
         RT_HIP(ctx, hipStreamSynchronize(st));
-        ctx->grid = rt_q16_grid(ctx->rootBox.min, ctx->rootBox.max);
+        ctx->grid = rt_qh_grid(ctx->rootBox.min, ctx->rootBox.max);
 
         // ---- the tree the rays walk: same pipeline, keys on a fine grid over the scene's own box
         const RtKeyPlan plan = rt_key_plan(ctx->rootBox.min, ctx->rootBox.max);
         rt_timer_begin(ctx, "k_fine_keys");
         hipLaunchKernelGGL(k_fine_keys, gridN, blk, 0, st, N, (const float4 *)ctx->dTriAABB, plan, wKeys, wSortedIdx);
         rt_timer_end(ctx);
-        if ((rc = build_tree_from_keys(ctx, sc, N, wKeys, wSortedIdx, wCodes, wLeft, wRight, wParent, wLeafParent, nullptr, wBvhData, wNodes)))
+        if ((rc = build_tree_from_keys(ctx, sc, N, wKeys, wSortedIdx, wCodes, wLeft, wRight, wParent, wLeafParent, nullptr, wBvhData, nullptr)))
             return rc;
         if (N >= 3) {
             for (int pass = 0; pass < RT_ROTATION_PASSES; ++pass) {
@@ -866,13 +838,10 @@ int rt_build_impl(RtContext *ctx)
                 });
                 if (rc) return rc;
             }
-            rt_timer_begin(ctx, "k_emit_nodes");
-            hipLaunchKernelGGL(k_emit_nodes, gridNI, blk, 0, st, N, wLeft, wRight, wSortedIdx, (const float4 *)ctx->dTriAABB,
-                               (const float4 *)wBvhData, (float4 *)wNodes);
-            rt_timer_end(ctx);
         }
-        rt_timer_begin(ctx, "k_quantise");
-        hipLaunchKernelGGL(k_quantise, gridNI, blk, 0, st, NI, ctx->grid, wNodes, (uint4 *)ctx->dQNodes, ctx->dErrorFlag);
+        rt_timer_begin(ctx, "k_emit_qnodes");
+        hipLaunchKernelGGL(k_emit_qnodes, gridNI, blk, 0, st, N, ctx->grid, wLeft, wRight, wSortedIdx, (const float4 *)ctx->dTriAABB,
+                           (const float4 *)wBvhData, (uint4 *)ctx->dQNodes, ctx->dErrorFlag);
         rt_timer_end(ctx);
         rt_timer_begin(ctx, "k_pack_leaves");
         hipLaunchKernelGGL(k_pack_leaves, gridN, blk, 0, st, N, wSortedIdx, ctx->dIdx, (const float *)ctx->dVerts, ctx->dMatIdx, ctx->dShadow,
@@ -903,7 +872,7 @@ int rt_build_impl(RtContext *ctx)
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     void *scratch[] = {sc.keysB, sc.valsB, sc.blockHist, sc.scanSums, sc.done, sc.undone[0], sc.undone[1], sc.undoneCount, wKeys, wCodes, wSortedIdx, wLeft, wRight, wParent,
-                       wLeafParent, refSize, walkLeafOfTri, wBvhData, wNodes};
+                       wLeafParent, refSize, walkLeafOfTri, wBvhData};
     for (void *q : scratch) (void)hipFree(q);
     ctx->built = true;
     return RT_OK;

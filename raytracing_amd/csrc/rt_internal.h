@@ -12,7 +12,7 @@
 #include <vector>
 
 #include "../../include/rt_math.h"
-#include "../../include/rt_q16.h"
+#include "../../include/rt_qh.h"
 #include "../../include/rtcore.h"
 
 #define RT_LEAF_BIT 0x80000000u
@@ -27,16 +27,15 @@ struct __attribute__((aligned(16))) RtNode64 {
     float lmin[3], lmax[3];
     float rmin[3], rmax[3];
     uint32_t left, right;      // index | RT_LEAF_BIT
-    uint32_t pad0, pad1;
+    uint32_t parent, pad1;     // RT_INVALID at the root (the exact walk climbs by it instead of keeping a stack)
 };
 static_assert(sizeof(RtNode64) == 64, "node layout");
 
-// The node the one-ray-per-lane walker reads, 32 B: both children's boxes on the
-// 16-bit grid of rt_q16.h (each CONTAINS the exact box of RtNode64).
-// box words: lo.x | lo.y << 16,  lo.z | hi.x << 16,  hi.y | hi.z << 16
+// The node the one-ray-per-lane walker reads, 32 B: both children's boxes as half-float planes on the
+// grid of rt_qh.h (each CONTAINS the exact box of RtNode64), one word per axis = low plane | high plane << 16.
 struct __attribute__((aligned(16))) RtQNode {
-    uint32_t lbox[3], rbox0;
-    uint32_t rbox1, rbox2, left, right;   // index | RT_LEAF_BIT
+    uint32_t lbox[3], rbox0;               // left box x, y, z; right box x
+    uint32_t rbox1, rbox2, left, right;   // right box y, z; children = index | RT_LEAF_BIT
 };
 static_assert(sizeof(RtQNode) == 32, "quantised node layout");
 

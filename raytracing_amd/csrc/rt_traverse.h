@@ -21,11 +21,14 @@
 //     therefore walks a second tree, built from finer keys than the reference's
 //     (include/rt_finekey.h) and reshaped by tree rotations (include/rt_rotate.h),
 //     through 32-byte nodes whose child boxes are rounded
-//     OUTWARD onto a 16-bit grid (rt_q16.h), with a cheap test that may say "maybe"
-//     but never a wrong "no"; the triangle's own box is exact and gets the
-//     reference's test.  Rays outside the monotone case (a zero / infinite / NaN
-//     component) walk the reference's own tree, exact 64-byte nodes with the
-//     reference's test at every node, and so does the packet walker.
+//     OUTWARD onto half-float planes (rt_qh.h): a plane's slab value is one
+//     v_fma_mix_f32, and when all rays of the wave run the same way along each axis
+//     (the usual case for camera and shadow rays) near and far planes are picked
+//     without min / max -- a test that may say "maybe" but never a wrong "no"; the
+//     triangle's own box is exact and gets the reference's test.  Rays outside the
+//     monotone case (a zero / infinite / NaN component) walk the reference's own
+//     tree, exact 64-byte nodes with the reference's test at every node and no stack
+//     (exact_walk), and so does the packet walker (with its own stacks).
 //   * the reference's slab test is first evaluated with per-ray reciprocals and an
 //     error margin; only when the margin cannot decide (a graze within a few ulp,
 //     an infinity, a NaN) are the six true divisions evaluated, so the boolean is
@@ -236,6 +239,131 @@ struct RayFeed {
     }
 };
 
+// The reference's own walk for ONE ray, exact 64-byte nodes of the reference's tree, the reference's test at
+// every box, its order (left leaf, right leaf, right subtree, left subtree) -- for the rare rays outside the
+// monotone case.  No stack: on the way back up the parent link says where the walk came from; from a right
+// subtree the left sibling is next if it is internal and passes (its box is tested again, same boolean), from a
+// left subtree the climb goes on.
+template <bool COUNT>
+__device__ __forceinline__ void exact_walk(const RtSceneView &sv, const rt_f3 o, const rt_f3 d, const rt_f3 r, RtHitRec &h, uint32_t cnt[3])
+{
+    if (sv.nTriangles == 0) return;
+    if (COUNT) cnt[0]++;
+    const RtAABB &rb = sv.rootBox;
+    if (sv.nTriangles < 2 || !box_hit_exact(rb.min[0], rb.min[1], rb.min[2], rb.max[0], rb.max[1], rb.max[2], o, d)) return;
+    uint32_t node = 0;
+    for (;;) {
+        const float4 *np = (const float4 *)(sv.nodes + node);
+        const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+        const uint32_t l = __float_as_uint(q3.x), rr = __float_as_uint(q3.y);
+        const bool lLeaf = (l & RT_LEAF_BIT) != 0, rLeaf = (rr & RT_LEAF_BIT) != 0;
+        const bool hitL = box_hit_exact(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, d);
+        const bool hitR = box_hit_exact(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, d);
+        if (COUNT) cnt[0] += 2u;
+        if (lLeaf && hitL) {
+            const bool boxed = tri_test<COUNT>(sv, l & ~RT_LEAF_BIT, o, d, r, h);
+            if (COUNT) { cnt[1]++; cnt[2] += boxed ? 1u : 0u; }
+        }
+        if (rLeaf && hitR) {
+            const bool boxed = tri_test<COUNT>(sv, rr & ~RT_LEAF_BIT, o, d, r, h);
+            if (COUNT) { cnt[1]++; cnt[2] += boxed ? 1u : 0u; }
+        }
+        if (!rLeaf && hitR) { node = rr; continue; }
+        if (!lLeaf && hitL) { node = l; continue; }
+        // nothing below: climb until a left sibling is still to be walked
+        uint32_t parent = __float_as_uint(q3.z);
+        for (;;) {
+            if (parent == RT_INVALID) return;
+            const float4 *pp = (const float4 *)(sv.nodes + parent);
+            const float4 p0 = pp[0], p1 = pp[1], p3 = pp[3];
+            const uint32_t pl = __float_as_uint(p3.x), pr = __float_as_uint(p3.y);
+            const bool fromRight = pr == node;                         // `node` is internal, so this names the right child
+            node = parent;
+            parent = __float_as_uint(p3.z);
+            if (fromRight && !(pl & RT_LEAF_BIT) && box_hit_exact(p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, o, d)) {
+                node = pl;
+                break;
+            }
+        }
+    }
+}
+
+// Per-lane state of the walk through the half-float nodes.
+struct WalkState {
+    uint32_t node, sp, npend, tos, below;
+    bool popped;
+};
+
+// The node phase of a wave: walk the tree, queue triangles whose box may pass.  A lane whose pending list has no
+// room for two more entries waits; the phase ends when too few lanes are still walking (the others wait for
+// triangle tests, a refill or retirement).  OCT < 8: every ray of the wave that is in the tree runs the same way
+// along each axis (rt_slab_octant) and the box test picks near and far planes without min / max; OCT == 8: any mix.
+template <uint32_t OCT, bool COUNT>
+__device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySlab &slab, WalkState &w, uint32_t *stk, uint32_t *pend,
+                                           uint32_t *spill, const uint32_t spillLanes, uint32_t cnt[3], const bool feedExhausted)
+{
+    for (;;) {
+        const bool act = w.node != TRV_DONE && w.npend <= TRV_PEND_CAP - 2;
+        const uint32_t nAct = (uint32_t)__popcll(__ballot(act));
+        const uint32_t nBusy = (uint32_t)__popcll(__ballot(w.node != TRV_DONE));
+        if (nAct == 0u || nAct * TRV_WALK_DEN < nBusy * TRV_WALK_NUM || (!feedExhausted && nBusy < 64u - TRV_REFILL_MIN)) break;
+        if (act) {
+            const uint4 *np = (const uint4 *)(sv.qnodes + w.node);
+            uint4 qa = np[0], qb = np[1];
+            w.tos = w.popped ? w.below : w.tos;                  // after the loads are on their way
+            w.popped = false;
+            // keep the fetch at two 16-byte loads per lane (the compiler would otherwise split the second)
+            asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));
+            const uint32_t l = qb.z, rr = qb.w;
+            const bool hitL = OCT < 8u ? rt_slab_maybe_octant<(OCT & 7u)>(slab, qa.x, qa.y, qa.z) : rt_slab_maybe(slab, qa.x, qa.y, qa.z);
+            const bool hitR = OCT < 8u ? rt_slab_maybe_octant<(OCT & 7u)>(slab, qa.w, qb.x, qb.y) : rt_slab_maybe(slab, qa.w, qb.x, qb.y);
+            const bool lLeaf = (l & RT_LEAF_BIT) != 0, rLeaf = (rr & RT_LEAF_BIT) != 0;
+            if (COUNT) cnt[0] += 2u;
+            // Straight-line bookkeeping: every store below happens whether or not it is needed
+            // (a slot past the end of a list is scratch), only the counters are conditional.
+            pend[w.npend * TRV_THREADS] = l & ~RT_LEAF_BIT;
+            w.npend += (lLeaf && hitL) ? 1u : 0u;
+            pend[w.npend * TRV_THREADS] = rr & ~RT_LEAF_BIT;
+            w.npend += (rLeaf && hitR) ? 1u : 0u;
+            const bool goL = !lLeaf && hitL, goR = !rLeaf && hitR;
+            if (__builtin_expect(w.sp < TRV_STACK_LDS, 1)) {
+                // `tos` mirrors level sp-1 in a register, so a pop needs no LDS round trip before
+                // the next node can be fetched; the level below is read now and taken over at the
+                // start of this lane's next step (level 0 holds TRV_DONE).
+                stk[w.sp * TRV_THREADS] = l;                         // right first, left later
+                w.below = stk[(w.sp > 1u ? w.sp - 2u : 0u) * TRV_THREADS];
+                const bool both = goL && goR, none = !(goL || goR);
+                uint32_t next = goR ? rr : l;
+                next = none ? w.tos : next;
+                w.node = next;
+                w.tos = both ? l : w.tos;
+                w.popped = none;
+                w.sp += both ? 1u : 0u;
+                w.sp -= none ? 1u : 0u;
+            } else {                                                 // deep levels live in HBM
+                w.node = goR ? rr : l;
+                if (goL && goR) {
+                    if (w.sp < RT_STACK_DEPTH) {
+                        spill[(size_t)(w.sp - TRV_STACK_LDS) * spillLanes] = l;
+                        w.sp++;
+                        w.tos = l;
+                    } else {                                         // deeper than the spill area
+                        *sv.errorFlag = 1u;
+                        w.node = TRV_DONE;
+                        w.sp = 1;
+                        w.tos = TRV_DONE;
+                    }
+                } else if (!(goL || goR)) {
+                    w.node = w.tos;
+                    w.sp--;
+                    const uint32_t lvl = w.sp ? w.sp - 1u : 0u;
+                    w.tos = lvl < TRV_STACK_LDS ? stk[lvl * TRV_THREADS] : spill[(size_t)(lvl - TRV_STACK_LDS) * spillLanes];
+                }
+            }
+        }
+    }
+}
+
 // Persistent traversal of `src.count()` rays by the waves of the launch (*cursor is 0 at launch).
 //   Src: uint32_t count(); void load(uint32_t i, rt_f3 &o, rt_f3 &d); void store(uint32_t i, const RtHitRec &h);
 // lds: TRV_LDS_WORDS words per block; this lane's first TRV_STACK_LDS stack levels are
@@ -253,9 +381,11 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
     RayFeed feed;
     feed.init(cursor, src.count());
 
-    bool hasRay = false, odd = false, popped = false;
+    bool hasRay = false;
     uint32_t firstHit = 0;      // does this ray's first hit settle its answer: 0 not asked yet, 1 yes, 2 no
-    uint32_t rayIdx = 0, node = TRV_DONE, sp = 0, npend = 0, tos = TRV_DONE, below = TRV_DONE;
+    uint32_t rayIdx = 0;
+    WalkState w;
+    w.node = TRV_DONE; w.sp = 0; w.npend = 0; w.tos = TRV_DONE; w.below = TRV_DONE; w.popped = false;
     rt_f3 o = rt_splat3(0.0f), d = rt_splat3(0.0f), r = rt_splat3(0.0f);
     RtRaySlab slab;
     memset(&slab, 0, sizeof slab);
@@ -266,7 +396,7 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
 
 #ifdef TRV_PROFILE
     // phase clocks of this wave (shader clock), reported through sv.stats[16..]
-    unsigned long long pT[4] = {0, 0, 0, 0}, pN[6] = {0, 0, 0, 0, 0, 0}, pS[3] = {0, 0, 0}, pMark = clock64();
+    unsigned long long pT[4] = {0, 0, 0, 0}, pN[6] = {0, 0, 0, 0, 0, 0}, pMark = clock64();
 #define TRV_PHASE(k) { const unsigned long long now_ = clock64(); pT[k] += now_ - pMark; pMark = now_; }
 #else
 #define TRV_PHASE(k)
@@ -281,23 +411,25 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                 rayIdx = mine;
                 src.load(mine, o, d);
                 r = rt_mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                odd = rt_ray_needs_exact_walk(o, d);
-                firstHit = 0;
                 slab = rt_ray_slab(sv.grid, o, r);
                 h.t = rt_inf(); h.u = 0.0f; h.v = 0.0f; h.leaf = RT_INVALID;
                 hasRay = true;
+                firstHit = 0;
                 stk[0] = TRV_DONE;                             // what the last pop of a ray returns
-                sp = 1;
-                tos = TRV_DONE;
-                popped = false;
-                npend = 0;
-                node = TRV_DONE;
+                w.sp = 1;
+                w.tos = TRV_DONE;
+                w.popped = false;
+                w.npend = 0;
+                w.node = TRV_DONE;
                 if (COUNT) nRays++;
-                if (sv.nTriangles != 0) {
+                if (__builtin_expect(rt_ray_needs_exact_walk(o, d) || !rt_slab_finite(slab), 0)) {
+                    exact_walk<COUNT>(sv, o, d, r, h, cnt);    // the whole walk, now; retired below
+                    firstHit = 2u;
+                } else if (sv.nTriangles != 0) {
                     if (COUNT) cnt[0]++;
                     const RtAABB &rb = sv.rootBox;
                     if (sv.nTriangles >= 2 && box_hit(rb.min[0], rb.min[1], rb.min[2], rb.max[0], rb.max[1], rb.max[2], o, d, r))
-                        node = 0;
+                        w.node = 0;
                 }
             }
         }
@@ -307,110 +439,28 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
         pN[0]++;
 #endif
 
-        // ---- node phase: walk the tree, queue triangles whose box passes.  A lane whose
-        // pending list has no room for two more entries waits; the phase ends when too few
-        // lanes are still walking (the others wait for triangle tests, a refill or retirement).
-        for (;;) {
-            const bool act = node != TRV_DONE && npend <= TRV_PEND_CAP - 2;
-            const unsigned long long am = __ballot(act);
-            const uint32_t nAct = (uint32_t)__popcll(am);
-            const uint32_t nBusy = (uint32_t)__popcll(__ballot(node != TRV_DONE));
-            if (nAct == 0u || nAct * TRV_WALK_DEN < nBusy * TRV_WALK_NUM || (!feed.exhausted && nBusy < 64u - TRV_REFILL_MIN)) break;
-#ifdef TRV_PROFILE
-            pN[1]++;
-            pN[2] += (unsigned long long)nAct;
-#endif
-#ifdef TRV_PROFILE
-            const unsigned long long q0_ = clock64();
-            unsigned long long q1_ = q0_, q2_ = q0_;
-#endif
-            if (act) {
-                uint32_t l, rr;
-                bool hitL, hitR;
-                if (__builtin_expect(!odd, 1)) {
-                    const uint4 *np = (const uint4 *)(sv.qnodes + node);
-                    uint4 qa = np[0], qb = np[1];
-                    tos = popped ? below : tos;                          // after the loads are on their way
-                    popped = false;
-                    // keep the fetch at two 16-byte loads per lane (the compiler would otherwise split the second)
-                    asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));
-#ifdef TRV_PROFILE
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    asm volatile("" : "+v"(qa.x), "+v"(qa.y), "+v"(qa.z), "+v"(qa.w));
-                    q1_ = clock64();
-#endif
-                    l = qb.z;
-                    rr = qb.w;
-                    hitL = rt_slab_maybe(slab, qa.x, qa.y, qa.z);
-                    hitR = rt_slab_maybe(slab, qa.w, qb.x, qb.y);
-#ifdef TRV_PROFILE
-                    asm volatile("" :: "s"(__ballot(hitL)), "s"(__ballot(hitR)));
-                    q2_ = clock64();
-#endif
-                } else {
-                    const float4 *np = (const float4 *)(sv.nodes + node);
-                    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-                    tos = popped ? below : tos;
-                    popped = false;
-                    l = __float_as_uint(q3.x);
-                    rr = __float_as_uint(q3.y);
-                    hitL = box_hit_exact(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, d);
-                    hitR = box_hit_exact(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, d);
-                }
-                const bool lLeaf = (l & RT_LEAF_BIT) != 0, rLeaf = (rr & RT_LEAF_BIT) != 0;
-                if (COUNT) cnt[0] += 2u;
-                // Straight-line bookkeeping: every store below happens whether or not it is needed
-                // (a slot past the end of a list is scratch), only the counters are conditional.
-                pend[npend * TRV_THREADS] = l & ~RT_LEAF_BIT;
-                npend += (lLeaf && hitL) ? 1u : 0u;
-                pend[npend * TRV_THREADS] = rr & ~RT_LEAF_BIT;
-                npend += (rLeaf && hitR) ? 1u : 0u;
-                const bool goL = !lLeaf && hitL, goR = !rLeaf && hitR;
-                if (__builtin_expect(sp < TRV_STACK_LDS, 1)) {
-                    // `tos` mirrors level sp-1 in a register, so a pop needs no LDS round trip before
-                    // the next node can be fetched; the level below is read now and taken over at the
-                    // start of this lane's next step (level 0 holds TRV_DONE).
-                    stk[sp * TRV_THREADS] = l;                           // right first, left later
-                    below = stk[(sp > 1u ? sp - 2u : 0u) * TRV_THREADS];
-                    const bool both = goL && goR, none = !(goL || goR);
-                    node = goR ? rr : l;
-                    node = none ? tos : node;
-                    tos = both ? l : tos;
-                    popped = none;
-                    sp += both ? 1u : 0u;
-                    sp -= none ? 1u : 0u;
-                } else {                                                 // deep levels live in HBM
-                    node = goR ? rr : l;
-                    if (goL && goR) {
-                        if (sp < RT_STACK_DEPTH) {
-                            spill[(size_t)(sp - TRV_STACK_LDS) * spillLanes] = l;
-                            sp++;
-                            tos = l;
-                        } else {                                         // deeper than any tree the build makes
-                            *sv.errorFlag = 1u;
-                            node = TRV_DONE;
-                            sp = 1;
-                            tos = TRV_DONE;
-                        }
-                    } else if (!(goL || goR)) {
-                        node = tos;
-                        sp--;
-                        const uint32_t lvl = sp ? sp - 1u : 0u;
-                        tos = lvl < TRV_STACK_LDS ? stk[lvl * TRV_THREADS] : spill[(size_t)(lvl - TRV_STACK_LDS) * spillLanes];
-                    }
-                }
+        // ---- node phase, in the variant for the way the wave's rays run
+        {
+            const unsigned long long in = __ballot(w.node != TRV_DONE);
+            const unsigned long long sx = __ballot(slab.A[0] < 0.0f) & in, sy = __ballot(slab.A[1] < 0.0f) & in, sz = __ballot(slab.A[2] < 0.0f) & in;
+            const bool uniform = (sx == 0ull || sx == in) && (sy == 0ull || sy == in) && (sz == 0ull || sz == in);
+            const uint32_t oct = uniform ? ((sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u)) : 8u;
+            switch (oct) {
+            case 0: node_phase<0, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
+            case 1: node_phase<1, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
+            case 2: node_phase<2, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
+            case 3: node_phase<3, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
+            case 4: node_phase<4, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
+            case 5: node_phase<5, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
+            case 6: node_phase<6, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
+            case 7: node_phase<7, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
+            default: node_phase<8, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
             }
-#ifdef TRV_PROFILE
-            {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                const unsigned long long q3_ = clock64();
-                pS[0] += q1_ - q0_; pS[1] += q2_ - q1_; pS[2] += q3_ - q2_;
-            }
-#endif
         }
 
         TRV_PHASE(1)
         // ---- triangle phase: every lane tests its queued triangles in the order it met them
+        const uint32_t npend = w.npend;
         if (COUNT) {
             for (uint32_t k = 0; __ballot(k < npend) != 0ull; ++k)
                 if (k < npend) {
@@ -450,15 +500,15 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                 }
             }
         }
-        npend = 0;
-        if (Src::FIRST_HIT_MAY_DECIDE && hasRay && h.leaf != RT_INVALID && node != TRV_DONE && firstHit != 2u) {
-            if (firstHit == 0u) firstHit = (!odd && src.first_hit_decides(o, d, r)) ? 1u : 2u;
-            if (firstHit == 1u) node = TRV_DONE;               // retired below
+        w.npend = 0;
+        if (Src::FIRST_HIT_MAY_DECIDE && hasRay && h.leaf != RT_INVALID && w.node != TRV_DONE && firstHit != 2u) {
+            if (firstHit == 0u) firstHit = src.first_hit_decides(o, d, r) ? 1u : 2u;
+            if (firstHit == 1u) w.node = TRV_DONE;             // retired below
         }
         TRV_PHASE(2)
 
         // ---- retire finished rays
-        if (hasRay && node == TRV_DONE) {
+        if (hasRay && w.node == TRV_DONE) {
             src.store(rayIdx, h);
             if (COUNT && h.leaf != RT_INVALID) nHits++;
             hasRay = false;
@@ -469,7 +519,6 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
     if (lane == 0) {
         for (int k = 0; k < 4; ++k) atomicAdd(&sv.stats[16 + k], pT[k]);
         for (int k = 0; k < 6; ++k) atomicAdd(&sv.stats[20 + k], pN[k]);
-        for (int k = 0; k < 3; ++k) atomicAdd(&sv.stats[26 + k], pS[k]);
     }
 #endif
     if (COUNT) flush_counters(sv, nRays, cnt, nHits);

@@ -190,7 +190,7 @@ def test_bvh_traversal_equals_brute_force(oracle):
 
 @pytest.mark.parametrize("name", ["cornell", "soup", "car", "dups", "far"])
 def test_grid_walk_returns_the_reference_walks_hits(oracle, name):
-    """The library walks 16-bit outward-rounded boxes with a may-pass test and keeps only the
+    """The library walks half-float outward-rounded boxes with a may-pass test and keeps only the
     triangle's own box exact.  That must not change a single hit: same triangle, same t/u/v bits
     as the reference's walk, same number of triangles whose own box passed; it may only test
     more boxes."""
@@ -228,6 +228,10 @@ def test_grid_walk_returns_the_reference_walks_hits(oracle, name):
     assert (ref["triangle"] != 0xFFFFFFFF).sum() > 50
 
 
+def _half_values(bits):
+    return bits.astype(np.uint16).view(np.float16).astype(np.float32)
+
+
 def test_grid_boxes_contain_the_exact_boxes(oracle):
     sc = scenes.car_standin(32, 32, detail=0.03)
     orc = oracle.Oracle(sc).build()
@@ -237,21 +241,26 @@ def test_grid_boxes_contain_the_exact_boxes(oracle):
     bvh["tri_aabb"] = orc.readback_bvh()["tri_aabb"]
     org, step = g[:3], g[3:]
     nodes, leaves = bvh["internal"], bvh["leaves"]
+
+    def step_key(bits, delta):                        # the next / previous finite half in value order
+        key = np.where(bits & 0x8000, -(bits & 0x7FFF).astype(np.int64), (bits & 0x7FFF).astype(np.int64)) + delta
+        key = np.clip(key, -31743, 31743)
+        return np.where(key >= 0, key, 0x8000 | -key).astype(np.uint32)
+
     for side, off in (("left", 0), ("right", 3)):
         child = nodes[side + "Node"]
         is_leaf = nodes[side + "NodeType"] != 0        # RT_INTERNAL_NODE = 0
         tri = bvh["sorted_index"][leaves["index"][np.where(is_leaf, child, 0)]]
         mn = np.where(is_leaf[:, None], bvh["tri_aabb"]["min"][tri], bvh["bvh_data"]["min"][np.where(is_leaf, 0, child)])
         mx = np.where(is_leaf[:, None], bvh["tri_aabb"]["max"][tri], bvh["bvh_data"]["max"][np.where(is_leaf, 0, child)])
-        w = q[:, off:off + 3]
-        lo = np.stack([w[:, 0] & 0xFFFF, w[:, 0] >> 16, w[:, 1] & 0xFFFF], 1)
-        hi = np.stack([w[:, 1] >> 16, w[:, 2] & 0xFFFF, w[:, 2] >> 16], 1)
-        plo = org + lo.astype(np.float32) * step      # float32 arithmetic, the walker's own expression
-        phi = org + hi.astype(np.float32) * step
+        w = q[:, off:off + 3]                          # one word per axis: low plane | high plane << 16, as binary16
+        lo, hi = w & 0xFFFF, w >> 16
+        plo = org + _half_values(lo) * step            # float32 arithmetic, the expression the build checks with
+        phi = org + _half_values(hi) * step
         assert plo.dtype == np.float32 and (plo <= mn).all() and (phi >= mx).all()
-        # ... and tight: one cell further in would cut into the exact box
-        assert ((org + (lo + 1).astype(np.float32) * step > mn) | (lo == 65535)).all()
-        assert ((org + np.maximum(hi.astype(np.int64) - 1, 0).astype(np.float32) * step < mx) | (hi == 0)).all()
+        # ... and tight: one grid plane further in would cut into the exact box
+        assert ((org + _half_values(step_key(lo, 1)) * step > mn) | (step == 0)).all()
+        assert ((org + _half_values(step_key(hi, -1)) * step < mx) | (step == 0)).all()
 
 
 def test_backface_culling_and_single_triangle(oracle):

@@ -45,6 +45,21 @@ __global__ __launch_bounds__(256) void k_valu(float *out, uint32_t iters, float 
 
 // Dependent gathers: every lane follows its own chain through a table of `n` 32-byte records; LOADS = 16-byte loads per step
 // (1: the first half of the record, 2: both halves), the next index comes out of the loaded words.
+// lanes of every group of GROUP consecutive lanes follow the same chain (same addresses in the same instruction)
+template <int GROUP>
+__global__ __launch_bounds__(256) void k_gather_group(const uint4 *__restrict__ table, uint32_t mask, uint32_t steps, uint32_t *out)
+{
+    uint32_t idx = ((blockIdx.x * 256u + threadIdx.x) / GROUP) * 2654435761u;
+    uint32_t acc = 0;
+    for (uint32_t s = 0; s < steps; ++s) {
+        const uint32_t i = idx & mask;
+        const uint4 a = table[(size_t)i * 2];
+        acc += a.y;
+        idx = idx * 1664525u + a.x + 1013904223u;
+    }
+    out[blockIdx.x * 256u + threadIdx.x] = acc + idx;
+}
+
 template <int LOADS, bool LDS_TOP>
 __global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ table, uint32_t mask, uint32_t steps, uint32_t ldsMask, uint32_t *out)
 {
@@ -133,6 +148,19 @@ int main()
             const char *vn[4] = {"1 x 16 B", "2 x 16 B (one record)", "2 x 16 B, half the steps LDS", "all steps from global, LDS code present"};
             printf("gather table %6zu KB  %-40s %8.3f ms  %.2f lane-steps per clock per CU\n", bytes >> 10, vn[variant], ms,
                    laneSteps / (ms * 1e-3 * 2.4e9 * cus));
+        }
+        for (int grp = 0; grp < 4; ++grp) {
+            struct G { const uint4 *t; uint32_t mask, steps, blocks; uint32_t *out; int grp; } g = {table, n - 1, 2048, blocks, gout, grp};
+            const double ms = run([](void *p) {
+                G *g = (G *)p;
+                if (g->grp == 0) hipLaunchKernelGGL((k_gather_group<2>), dim3(g->blocks), dim3(256), 0, 0, g->t, g->mask, g->steps, g->out);
+                if (g->grp == 1) hipLaunchKernelGGL((k_gather_group<4>), dim3(g->blocks), dim3(256), 0, 0, g->t, g->mask, g->steps, g->out);
+                if (g->grp == 2) hipLaunchKernelGGL((k_gather_group<16>), dim3(g->blocks), dim3(256), 0, 0, g->t, g->mask, g->steps, g->out);
+                if (g->grp == 3) hipLaunchKernelGGL((k_gather_group<64>), dim3(g->blocks), dim3(256), 0, 0, g->t, g->mask, g->steps, g->out);
+            }, &g);
+            const int gs[4] = {2, 4, 16, 64};
+            printf("gather table %6zu KB  1 x 16 B, groups of %2d lanes share the address %8.3f ms  %.2f lane-steps per clock per CU\n", bytes >> 10, gs[grp], ms,
+                   (double)blocks * 256 * 2048 / (ms * 1e-3 * 2.4e9 * cus));
         }
         CHECK(hipFree(table));
     }
