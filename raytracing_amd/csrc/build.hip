@@ -337,20 +337,20 @@ __global__ __launch_bounds__(256) void k_tree(const uint32_t *__restrict__ codes
 // no atomics or fences are needed.  The union itself is min/max only, hence
 // identical to the reference's atomic-flag walk whatever the order.
 // (`list`: the nodes still to do, nullptr = all n of them; see compact_undone)
-__global__ __launch_bounds__(256) void k_fit(uint32_t n, const uint32_t *__restrict__ list, uint32_t iter, const uint32_t *__restrict__ left,
+__global__ __launch_bounds__(256) void k_fit(uint32_t nAll, const uint32_t *__restrict__ list, const uint32_t *__restrict__ listCount, uint32_t iter, const uint32_t *__restrict__ left,
                                               const uint32_t *__restrict__ right, const uint32_t *__restrict__ sortedIdx,
                                               const float4 *__restrict__ triAABB, float4 *bvhData, uint32_t *done,
                                               float4 *__restrict__ nodes, const uint32_t *__restrict__ parent)
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
+    const uint32_t n = list ? *listCount : nAll;          // the list's length stays on the device
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
     const uint32_t i = list ? list[k] : k;
-    if (done[i] != FIT_UNDONE) return;
+    if (done[i] != FIT_UNDONE) continue;
     const uint32_t l = left[i], r = right[i];
     const bool lLeaf = l & RT_LEAF_BIT, rLeaf = r & RT_LEAF_BIT;
     const uint32_t li = l & ~RT_LEAF_BIT, ri = r & ~RT_LEAF_BIT;
-    if (!lLeaf && done[li] >= iter) return;
-    if (!rLeaf && done[ri] >= iter) return;
+    if (!lLeaf && done[li] >= iter) continue;
+    if (!rLeaf && done[ri] >= iter) continue;
     float4 lmn, lmx, rmn, rmx;
     if (lLeaf) { const uint32_t t = sortedIdx[li]; lmn = triAABB[t * 2]; lmx = triAABB[t * 2 + 1]; }
     else       { lmn = bvhData[li * 2]; lmx = bvhData[li * 2 + 1]; }
@@ -365,55 +365,41 @@ __global__ __launch_bounds__(256) void k_fit(uint32_t n, const uint32_t *__restr
         nodes[i * 4 + 3] = make_float4(__uint_as_float(l), __uint_as_float(r), __uint_as_float(parent[i]), 0.0f);
     }
     done[i] = iter;
+    }
 }
 
 // A level-synchronous pass looks at every node in every launch although half of the nodes are done after the
 // first launch and seven eighths after the third.  From then on the launches run over a list of the nodes
 // still to do, renewed every few levels (the order of the list does not matter).
 #define COMPACT_THREADS 1024
-__global__ __launch_bounds__(COMPACT_THREADS) void k_compact_undone(uint32_t n, const uint32_t *__restrict__ listIn,
+__global__ __launch_bounds__(COMPACT_THREADS) void k_compact_undone(uint32_t nAll, const uint32_t *__restrict__ listIn, const uint32_t *__restrict__ countIn,
                                                                     const uint32_t *__restrict__ done, uint32_t *__restrict__ listOut,
                                                                     uint32_t *__restrict__ count)
 {
     __shared__ uint32_t waveBase[COMPACT_THREADS / 64];
     __shared__ uint32_t blockBase;
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t i = k < n ? (listIn ? listIn[k] : k) : 0u;
-    const bool keep = k < n && done[i] == FIT_UNDONE;
-    const unsigned long long m = __ballot(keep);
+    const uint32_t n = listIn ? *countIn : nAll;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (lane == 0) waveBase[wave] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {          // one atomic per block: atomics on one word are served one at a time
-        uint32_t total = 0;
-        for (uint32_t w = 0; w < COMPACT_THREADS / 64; ++w) {
-            const uint32_t c = waveBase[w];
-            waveBase[w] = total;
-            total += c;
+    for (uint32_t chunk = blockIdx.x * COMPACT_THREADS; chunk < n; chunk += gridDim.x * COMPACT_THREADS) {
+        const uint32_t k = chunk + threadIdx.x;
+        const uint32_t i = k < n ? (listIn ? listIn[k] : k) : 0u;
+        const bool keep = k < n && done[i] == FIT_UNDONE;
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) waveBase[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {          // one atomic per chunk: atomics on one word are served one at a time
+            uint32_t total = 0;
+            for (uint32_t w = 0; w < COMPACT_THREADS / 64; ++w) {
+                const uint32_t c = waveBase[w];
+                waveBase[w] = total;
+                total += c;
+            }
+            blockBase = total ? atomicAdd(count, total) : 0u;
         }
-        blockBase = total ? atomicAdd(count, total) : 0u;
+        __syncthreads();
+        if (keep) listOut[blockBase + waveBase[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
     }
-    __syncthreads();
-    if (keep) listOut[blockBase + waveBase[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
-}
-
-struct UndoneList {             // host side of the above: two lists that take turns, the count on the device and here
-    uint32_t *buf[2] = {nullptr, nullptr}, *dCount = nullptr;
-    const uint32_t *cur = nullptr;
-    uint32_t n = 0;
-    int which = 0;
-};
-
-static int compact_undone(RtContext *ctx, UndoneList &u, const uint32_t *done)
-{
-    hipStream_t st = ctx->stream;
-    RT_HIP(ctx, hipMemsetAsync(u.dCount, 0, 4, st));
-    if (u.n) hipLaunchKernelGGL(k_compact_undone, dim3((u.n + COMPACT_THREADS - 1) / COMPACT_THREADS), dim3(COMPACT_THREADS), 0, st, u.n, u.cur, done, u.buf[u.which], u.dCount);
-    RT_HIP(ctx, hipMemcpyAsync(&u.n, u.dCount, 4, hipMemcpyDeviceToHost, st));
-    RT_HIP(ctx, hipStreamSynchronize(st));
-    u.cur = u.buf[u.which];
-    u.which ^= 1;
-    return RT_OK;
 }
 
 // ------------------------------------------------------------------ tree rotations (traversal tree only)
@@ -436,18 +422,18 @@ __device__ __forceinline__ void load_box(uint32_t child, const uint32_t *__restr
     out[0] = mn.x; out[1] = mn.y; out[2] = mn.z; out[3] = mx.x; out[4] = mx.y; out[5] = mx.z;
 }
 
-__global__ __launch_bounds__(256) void k_rotate(uint32_t n, const uint32_t *__restrict__ list, uint32_t iter, uint32_t *left, uint32_t *right,
+__global__ __launch_bounds__(256) void k_rotate(uint32_t nAll, const uint32_t *__restrict__ list, const uint32_t *__restrict__ listCount, uint32_t iter, uint32_t *left, uint32_t *right,
                                                  const uint32_t *__restrict__ sortedIdx, const float4 *__restrict__ triAABB,
                                                  float4 *bvhData, uint32_t *done)
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
+    const uint32_t n = list ? *listCount : nAll;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
     const uint32_t i = list ? list[k] : k;
-    if (done[i] != FIT_UNDONE) return;
+    if (done[i] != FIT_UNDONE) continue;
     const uint32_t l = left[i], r = right[i];
     const bool lInt = !(l & RT_LEAF_BIT), rInt = !(r & RT_LEAF_BIT);
-    if (lInt && done[l] >= iter) return;
-    if (rInt && done[r] >= iter) return;
+    if (lInt && done[l] >= iter) continue;
+    if (rInt && done[r] >= iter) continue;
     float L[6], R[6], La[6] = {0, 0, 0, 0, 0, 0}, Lb[6] = {0, 0, 0, 0, 0, 0}, Ra[6] = {0, 0, 0, 0, 0, 0}, Rb[6] = {0, 0, 0, 0, 0, 0};
     uint32_t la = 0, lb = 0, ra = 0, rb = 0;
     load_box(l, sortedIdx, triAABB, bvhData, L);
@@ -482,20 +468,21 @@ __global__ __launch_bounds__(256) void k_rotate(uint32_t n, const uint32_t *__re
         bvhData[c * 2 + 0] = make_float4(m[0], m[1], m[2], 0.0f);
         bvhData[c * 2 + 1] = make_float4(m[3], m[4], m[5], 0.0f);
     } else if (which >= 5) {     // 5: La <-> Ra, 6: La <-> Rb: both children change
-        float n[6];
+        float n2[6];
         if (which == 5) {
             left[l] = ra; left[r] = la;
-            rt_box_merge(Ra, Lb, m); rt_box_merge(La, Rb, n);
+            rt_box_merge(Ra, Lb, m); rt_box_merge(La, Rb, n2);
         } else {
             left[l] = rb; right[r] = la;
-            rt_box_merge(Rb, Lb, m); rt_box_merge(Ra, La, n);
+            rt_box_merge(Rb, Lb, m); rt_box_merge(Ra, La, n2);
         }
         bvhData[l * 2 + 0] = make_float4(m[0], m[1], m[2], 0.0f);
         bvhData[l * 2 + 1] = make_float4(m[3], m[4], m[5], 0.0f);
-        bvhData[r * 2 + 0] = make_float4(n[0], n[1], n[2], 0.0f);
-        bvhData[r * 2 + 1] = make_float4(n[3], n[4], n[5], 0.0f);
+        bvhData[r * 2 + 0] = make_float4(n2[0], n2[1], n2[2], 0.0f);
+        bvhData[r * 2 + 1] = make_float4(n2[3], n2[4], n2[5], 0.0f);
     }
     done[i] = iter;
+    }
 }
 
 // ------------------------------------------------------------------ half-float traversal nodes
@@ -673,29 +660,48 @@ static hipError_t dalloc(T **p, size_t count)
 // Scratch shared by the two passes of the pipeline.
 struct BuildScratch {
     uint32_t *keysB = nullptr, *valsB = nullptr, *blockHist = nullptr, *scanSums = nullptr, *done = nullptr;
-    uint32_t *undone[2] = {nullptr, nullptr}, *undoneCount = nullptr;
+    uint32_t *undone[2] = {nullptr, nullptr}, *counts = nullptr;   // counts: PASS_COUNT_WORDS words, one per compaction of the build
+    uint32_t nextCount = 0, finalCount[32], nFinal = 0;           // the words that must read 0 when the build has finished
     uint32_t nbSort = 0, histLen = 0;
 };
 
-// One bottom-up pass over the NI internal nodes: launch(n, list, iter) until no node is left undone.
+// One bottom-up pass over the NI internal nodes, a launch per tree level: launch(blocks, list, listCount, iter).
+// From the third level on the launches run over a list of the nodes still to do, renewed every six levels; the
+// length of a list stays on the device (every compaction has a count word of its own in sc.counts, zeroed once per
+// build), the launches over it are grid-stride loops of a size the host only estimates, so no level waits for the
+// host.  PASS_LEVELS levels are launched whatever the tree's height (a Karras tree over unique 32-bit keys has at
+// most 32, a rotation pass can add one); the count of what is then still undone is looked at when the build ends.
+#define PASS_LEVELS 50u
+#define PASS_COUNT_WORDS 256u
 template <class Launch>
-static int run_levels(RtContext *ctx, BuildScratch &sc, uint32_t NI, const char *what, Launch launch)
+static int run_levels(RtContext *ctx, BuildScratch &sc, uint32_t NI, Launch launch)
 {
-    RT_HIP(ctx, hipMemsetAsync(sc.done, 0xFF, (size_t)NI * 4, ctx->stream));
-    UndoneList u;
-    u.buf[0] = sc.undone[0];
-    u.buf[1] = sc.undone[1];
-    u.dCount = sc.undoneCount;
-    u.n = NI;
-    // A Karras tree over unique 32-bit keys is at most 32 levels high; rotations can add a level per pass.
-    for (uint32_t iter = 0; u.n; ++iter) {
-        if (iter >= 4096) return rt_fail(ctx, RT_E_STATE, "%s did not reach the root", what);
-        launch(u.n, u.cur, iter);
+    hipStream_t st = ctx->stream;
+    RT_HIP(ctx, hipMemsetAsync(sc.done, 0xFF, (size_t)NI * 4, st));
+    const uint32_t *list = nullptr, *listCount = nullptr;
+    uint32_t expected = NI;       // a guess at the list's length, for the size of the launches only
+    int which = 0;
+    for (uint32_t iter = 0; iter < PASS_LEVELS; ++iter) {
+        const uint32_t blocks = list ? (expected + 255u) / 256u : (NI + 255u) / 256u;
+        launch(blocks < 64u ? 64u : blocks, list, listCount, iter);
         if (iter == 2 || (iter > 2 && (iter - 2) % 6 == 0)) {
-            const int rc = compact_undone(ctx, u, sc.done);
-            if (rc) return rc;
+            if (sc.nextCount >= PASS_COUNT_WORDS) return rt_fail(ctx, RT_E_STATE, "BVH build: out of count words");
+            uint32_t *count = sc.counts + sc.nextCount++;
+            const uint32_t cblocks = ((list ? expected : NI) + COMPACT_THREADS - 1) / COMPACT_THREADS;
+            hipLaunchKernelGGL(k_compact_undone, dim3(cblocks < 16u ? 16u : cblocks), dim3(COMPACT_THREADS), 0, st, NI, list, listCount, sc.done,
+                               sc.undone[which], count);
+            list = sc.undone[which];
+            listCount = count;
+            which ^= 1;
+            expected = iter == 2 ? NI / 4u : expected / 16u;
+            if (expected < 4096u) expected = 4096u;
         }
     }
+    // what is undone after the last level must be nothing: counted now, looked at by rt_build_impl after its final synchronisation
+    if (sc.nFinal >= 32 || sc.nextCount >= PASS_COUNT_WORDS) return rt_fail(ctx, RT_E_STATE, "BVH build: too many passes");
+    uint32_t *count = sc.counts + sc.nextCount++;
+    hipLaunchKernelGGL(k_compact_undone, dim3(16), dim3(COMPACT_THREADS), 0, st, NI, list, listCount, sc.done, sc.undone[which], count);
+    sc.finalCount[sc.nFinal++] = (uint32_t)(count - sc.counts);
     return RT_OK;
 }
 
@@ -733,9 +739,9 @@ static int build_tree_from_keys(RtContext *ctx, BuildScratch &sc, uint32_t N, ui
     rt_timer_begin(ctx, "k_tree");
     hipLaunchKernelGGL(k_tree, gridNI, blk, 0, st, codes, N, left, right, parent, leafParent, rangeSize);
     rt_timer_end(ctx);
-    return run_levels(ctx, sc, NI, "BVH fit", [&](uint32_t n, const uint32_t *list, uint32_t iter) {
+    return run_levels(ctx, sc, NI, [&](uint32_t blocks, const uint32_t *list, const uint32_t *listCount, uint32_t iter) {
         rt_timer_begin(ctx, "k_fit");
-        hipLaunchKernelGGL(k_fit, dim3((n + 255) / 256), blk, 0, st, n, list, iter, left, right, sortedIdx, (const float4 *)ctx->dTriAABB,
+        hipLaunchKernelGGL(k_fit, dim3(blocks), blk, 0, st, NI, list, listCount, iter, left, right, sortedIdx, (const float4 *)ctx->dTriAABB,
                            (float4 *)bvhData, sc.done, (float4 *)nodes, parent);
         rt_timer_end(ctx);
     });
@@ -782,7 +788,7 @@ int rt_build_impl(RtContext *ctx)
     RT_HIP(ctx, dalloc(&sc.done, (size_t)NI));
     RT_HIP(ctx, dalloc(&sc.undone[0], (size_t)NI));
     RT_HIP(ctx, dalloc(&sc.undone[1], (size_t)NI));
-    RT_HIP(ctx, dalloc(&sc.undoneCount, (size_t)1));
+    RT_HIP(ctx, dalloc(&sc.counts, (size_t)PASS_COUNT_WORDS));
     RT_HIP(ctx, dalloc(&wKeys, (size_t)N));
     RT_HIP(ctx, dalloc(&wCodes, (size_t)N));
     RT_HIP(ctx, dalloc(&wSortedIdx, (size_t)N));
@@ -799,6 +805,7 @@ int rt_build_impl(RtContext *ctx)
     RT_HIP(ctx, hipEventCreate(&e0));
     RT_HIP(ctx, hipEventCreate(&e1));
     RT_HIP(ctx, hipEventRecord(e0, st));
+    RT_HIP(ctx, hipMemsetAsync(sc.counts, 0, PASS_COUNT_WORDS * sizeof(uint32_t), st));
 
     const dim3 blk(256);
     const dim3 gridN((N + 255) / 256), gridNI((NI + 255) / 256);
@@ -830,9 +837,9 @@ int rt_build_impl(RtContext *ctx)
         if (N >= 3) {
             for (int pass = 0; pass < RT_ROTATION_PASSES; ++pass) {
                 // a rotation can lengthen a path by one level, so the height is no longer bounded by the key width
-                rc = run_levels(ctx, sc, NI, "tree rotation pass", [&](uint32_t n, const uint32_t *list, uint32_t iter) {
+                rc = run_levels(ctx, sc, NI, [&](uint32_t blocks, const uint32_t *list, const uint32_t *listCount, uint32_t iter) {
                     rt_timer_begin(ctx, "k_rotate");
-                    hipLaunchKernelGGL(k_rotate, dim3((n + 255) / 256), blk, 0, st, n, list, iter, wLeft, wRight, wSortedIdx,
+                    hipLaunchKernelGGL(k_rotate, dim3(blocks), blk, 0, st, NI, list, listCount, iter, wLeft, wRight, wSortedIdx,
                                        (const float4 *)ctx->dTriAABB, (float4 *)wBvhData, sc.done);
                     rt_timer_end(ctx);
                 });
@@ -864,14 +871,19 @@ int rt_build_impl(RtContext *ctx)
     }
 
     RT_HIP(ctx, hipEventRecord(e1, st));
+    uint32_t hostCounts[PASS_COUNT_WORDS];
+    RT_HIP(ctx, hipMemcpyAsync(hostCounts, sc.counts, sizeof hostCounts, hipMemcpyDeviceToHost, st));
     RT_HIP(ctx, hipStreamSynchronize(st));
     RT_HIP(ctx, hipGetLastError());
+    for (uint32_t k = 0; k < sc.nFinal; ++k)
+        if (hostCounts[sc.finalCount[k]] != 0u)
+            return rt_fail(ctx, RT_E_STATE, "BVH build: %u nodes of a bottom-up pass were still undone after %u levels", hostCounts[sc.finalCount[k]], PASS_LEVELS);
     float ms = 0;
     RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
     ctx->buildMs = ms;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    void *scratch[] = {sc.keysB, sc.valsB, sc.blockHist, sc.scanSums, sc.done, sc.undone[0], sc.undone[1], sc.undoneCount, wKeys, wCodes, wSortedIdx, wLeft, wRight, wParent,
+    void *scratch[] = {sc.keysB, sc.valsB, sc.blockHist, sc.scanSums, sc.done, sc.undone[0], sc.undone[1], sc.counts, wKeys, wCodes, wSortedIdx, wLeft, wRight, wParent,
                        wLeafParent, refSize, walkLeafOfTri, wBvhData};
     for (void *q : scratch) (void)hipFree(q);
     ctx->built = true;
