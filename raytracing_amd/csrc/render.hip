@@ -26,7 +26,8 @@
 #define Q_ITEMS 8
 #define Q_THREADS 256
 #define Q_TILE (Q_ITEMS * Q_THREADS)
-__device__ __forceinline__ void block_queue_flush(const uint32_t *stage, uint32_t *__restrict__ queue, uint32_t *__restrict__ count)
+template <class Emit>
+__device__ __forceinline__ void block_queue_flush(const uint32_t *stage, uint32_t *__restrict__ count, Emit emit)
 {
     __shared__ uint32_t wsum[Q_THREADS / 64];
     __shared__ uint32_t gbase;
@@ -51,9 +52,19 @@ __device__ __forceinline__ void block_queue_flush(const uint32_t *stage, uint32_
     __syncthreads();
     uint32_t base = gbase;
     for (uint32_t w = 0; w < wave; ++w) base += wsum[w];
-#pragma unroll
+#pragma unroll 1
     for (int it = 0; it < Q_ITEMS; ++it)
-        if (v[it] != RT_INVALID) queue[base + pre[it]] = v[it];
+        if (v[it] != RT_INVALID) emit(v[it], base + pre[it]);     // (what the entry stood for, its place in the queue)
+}
+
+// A queue entry IS the ray: 32 bytes in queue order, so that the walker's refill reads consecutive records
+// instead of gathering origin and direction through a slot number out of per-path arrays tens of gigabytes long.
+//   r0 = (origin.xyz, direction.x)   r1 = (direction.y, direction.z, path slot as bits, 0)
+// Hit records are kept by queue position as well (the shading pass walks the queue in the same order).
+__device__ __forceinline__ void ray_record_store(float4 *__restrict__ ray, uint32_t at, const rt_f3 o, const rt_f3 d, uint32_t slot)
+{
+    ray[2 * (size_t)at] = make_float4(o.x, o.y, o.z, d.x);
+    ray[2 * (size_t)at + 1] = make_float4(d.y, d.z, __uint_as_float(slot), 0.0f);
 }
 
 // ------------------------------------------------------------------ ray sources for traverse_rays
@@ -76,18 +87,17 @@ struct ArraySrc {            // caller rays (rt_trace_rays)
 struct QueueSrc {            // live paths of one bounce
     static constexpr bool FIRST_HIT_MAY_DECIDE = false;
     __device__ __forceinline__ bool first_hit_decides(const rt_f3, const rt_f3, const rt_f3) const { return false; }
-    const uint32_t *queue, *qcount;
-    const float4 *po, *pd;
-    RtHitRec *hit;
+    const float4 *ray;         // 2 x float4 per queue entry
+    const uint32_t *qcount;
+    RtHitRec *hit;             // by queue position
     __device__ __forceinline__ uint32_t count() const { return *qcount; }
     __device__ __forceinline__ void load(uint32_t i, rt_f3 &o, rt_f3 &d) const
     {
-        const uint32_t slot = queue[i];
-        const float4 o4 = po[slot], d4 = pd[slot];
-        o = rt_mk3(o4.x, o4.y, o4.z);
-        d = rt_mk3(d4.x, d4.y, d4.z);
+        const float4 r0 = ray[2 * (size_t)i], r1 = ray[2 * (size_t)i + 1];
+        o = rt_mk3(r0.x, r0.y, r0.z);
+        d = rt_mk3(r0.w, r1.x, r1.y);
     }
-    __device__ __forceinline__ void store(uint32_t i, const RtHitRec &h) const { hit[queue[i]] = h; }
+    __device__ __forceinline__ void store(uint32_t i, const RtHitRec &h) const { hit[i] = h; }
 };
 
 // The 16 soft-shadow rays of every shaded pixel (Shadow.cginc:95-111): ray
@@ -302,9 +312,8 @@ __global__ void k_pack_rays(const float *__restrict__ o3, const float *__restric
 // extension; ShadowMap: RT_FLAG_DEPTH_OF_FIELD as in the reference).
 template <uint32_t DOF_FLAG, bool CLEAR_RT>
 __global__ __launch_bounds__(Q_THREADS) void k_generate(RtTileMap tm, RtParams P, const float *__restrict__ seeds, uint32_t nFrames,
-                                                         float4 *__restrict__ po, float4 *__restrict__ pd, float4 *__restrict__ pe,
-                                                         float4 *__restrict__ img, uint2 *__restrict__ rng,
-                                                         uint32_t *__restrict__ queue, uint32_t *__restrict__ qcount)
+                                                         float4 *__restrict__ ray, float4 *__restrict__ pe,
+                                                         float4 *__restrict__ img, uint2 *__restrict__ rng, uint32_t *__restrict__ qcount)
 {
     __shared__ uint32_t stage[Q_TILE];
     const uint32_t total = tm.nSlots * nFrames;
@@ -321,23 +330,25 @@ __global__ __launch_bounds__(Q_THREADS) void k_generate(RtTileMap tm, RtParams P
         uint32_t px = 0, py = 0;
         const bool active = q < total && tm.slot_to_pixel(slot, &px, &py);
         if (q < total && (CLEAR_RT || !active)) img[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (active) {
-            rt_rng r;
-            rt_rng_init(&r, px, py, seeds[frame]);
-            const float r0 = rt_rand(&r), r1 = rt_rand(&r);
-            const float uvx = (((float)px + r0) - 0.5f) / (float)P.width * 2 - 1;
-            const float uvy = (((float)py + r1) - 0.5f) / (float)P.height * 2 - 1;
-            rt_f3 o, d;
-            if (P.flags & DOF_FLAG) d_dof_camera_ray(P, r, uvx, uvy, o, d);
-            else d_camera_ray(P, uvx, uvy, o, d);
-            po[g] = make_float4(o.x, o.y, o.z, 0.0f);
-            pd[g] = make_float4(d.x, d.y, d.z, 0.0f);
-            if (CLEAR_RT) pe[g] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-            rng[g] = make_uint2(r.state, __float_as_uint(r.seed));
-        }
         stage[it * Q_THREADS + threadIdx.x] = active ? g : RT_INVALID;
     }
-    block_queue_flush(stage, queue, qcount);
+    // the ray of an active path is made once its place in the queue is known, and written there
+    block_queue_flush(stage, qcount, [&](uint32_t g, uint32_t at) {
+        const uint32_t frame = g / tm.nSlots, slot = g % tm.nSlots;
+        uint32_t px = 0, py = 0;
+        tm.slot_to_pixel(slot, &px, &py);
+        rt_rng r;
+        rt_rng_init(&r, px, py, seeds[frame]);
+        const float r0 = rt_rand(&r), r1 = rt_rand(&r);
+        const float uvx = (((float)px + r0) - 0.5f) / (float)P.width * 2 - 1;
+        const float uvy = (((float)py + r1) - 0.5f) / (float)P.height * 2 - 1;
+        rt_f3 o, d;
+        if (P.flags & DOF_FLAG) d_dof_camera_ray(P, r, uvx, uvy, o, d);
+        else d_camera_ray(P, uvx, uvy, o, d);
+        ray_record_store(ray, at, o, d, g);
+        if (CLEAR_RT) pe[g] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+        rng[g] = make_uint2(r.state, __float_as_uint(r.seed));
+    });
 }
 
 // Gathers what CheckTriangle copies into RayHit on an accepted hit
@@ -381,10 +392,9 @@ __device__ __forceinline__ void load_hit(const RtSceneView &sv, const RtHitRec &
 // their own random stream, so the order they are shaded in changes no value.
 // BRUTE: the hit records come from k_brute_extend and name a primitive instead of a BVH leaf.
 template <bool SORT, bool BRUTE>
-__global__ __launch_bounds__(Q_THREADS) void k_shade(RtSceneView sv, RtBruteView bv, RtTileMap tm, RtParams P, int bounce, const uint32_t *__restrict__ queueIn,
-                                                const uint32_t *__restrict__ countIn, uint32_t *__restrict__ queueOut,
-                                                uint32_t *__restrict__ countOut, float4 *__restrict__ po,
-                                                float4 *__restrict__ pd, float4 *__restrict__ pe, float4 *__restrict__ rt,
+__global__ __launch_bounds__(Q_THREADS) void k_shade(RtSceneView sv, RtBruteView bv, RtTileMap tm, RtParams P, int bounce, float4 *__restrict__ rayIn,
+                                                const uint32_t *__restrict__ countIn, float4 *__restrict__ rayOut,
+                                                uint32_t *__restrict__ countOut, float4 *__restrict__ pe, float4 *__restrict__ rt,
                                                 uint2 *__restrict__ rng, const RtHitRec *__restrict__ hitRec)
 {
     __shared__ uint32_t stage[Q_TILE];
@@ -395,15 +405,15 @@ __global__ __launch_bounds__(Q_THREADS) void k_shade(RtSceneView sv, RtBruteView
     if (SORT) {
         if (threadIdx.x < 8) bin[threadIdx.x] = 0;
         __syncthreads();
-        uint32_t slots[Q_ITEMS], where[Q_ITEMS];
+        uint32_t entry[Q_ITEMS], where[Q_ITEMS];
 #pragma unroll
         for (int it = 0; it < Q_ITEMS; ++it) {
             const uint32_t i = blockIdx.x * Q_TILE + it * Q_THREADS + threadIdx.x;
             uint32_t key = 7u;                                   // past the end of the queue
-            slots[it] = RT_INVALID;
+            entry[it] = RT_INVALID;
             if (i < n) {
-                slots[it] = queueIn[i];
-                const uint32_t leaf = hitRec[slots[it]].leaf;
+                entry[it] = i;
+                const uint32_t leaf = hitRec[i].leaf;
                 key = 0u;                                        // miss
                 if (leaf != RT_INVALID) {
                     const uint32_t mi = __float_as_uint(((const float4 *)(sv.leafShade + leaf))[2].y);
@@ -420,23 +430,23 @@ __global__ __launch_bounds__(Q_THREADS) void k_shade(RtSceneView sv, RtBruteView
         }
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < Q_ITEMS; ++it) order[bin[where[it] >> 16] + (where[it] & 0xFFFFu)] = slots[it];
+        for (int it = 0; it < Q_ITEMS; ++it) order[bin[where[it] >> 16] + (where[it] & 0xFFFFu)] = entry[it];
         __syncthreads();
     }
 #pragma unroll 1
     for (int it = 0; it < Q_ITEMS; ++it) {
-    const uint32_t i = blockIdx.x * Q_TILE + it * Q_THREADS + threadIdx.x;
+    const uint32_t own = blockIdx.x * Q_TILE + it * Q_THREADS + threadIdx.x;
     bool alive = false;
-    uint32_t slot = 0;
-    const uint32_t sortedSlot = SORT ? order[it * Q_THREADS + threadIdx.x] : 0u;
-    if (SORT ? sortedSlot != RT_INVALID : i < n) {
-        slot = SORT ? sortedSlot : queueIn[i];
-        const float4 o4 = po[slot], d4 = pd[slot], e4 = pe[slot];
+    const uint32_t i = SORT ? order[it * Q_THREADS + threadIdx.x] : (own < n ? own : RT_INVALID);   // queue entry this thread shades
+    if (i != RT_INVALID) {
+        const float4 r0 = rayIn[2 * (size_t)i], r1 = rayIn[2 * (size_t)i + 1];
+        const uint32_t slot = __float_as_uint(r1.z);
+        const float4 e4 = pe[slot];
         float4 c4 = rt[slot];
-        const RtHitRec h = hitRec[slot];
+        const RtHitRec h = hitRec[i];
         DRay ray;
-        ray.origin = rt_mk3(o4.x, o4.y, o4.z);
-        ray.direction = rt_mk3(d4.x, d4.y, d4.z);
+        ray.origin = rt_mk3(r0.x, r0.y, r0.z);
+        ray.direction = rt_mk3(r0.w, r1.x, r1.y);
         ray.energy = rt_mk3(e4.x, e4.y, e4.z);
         rt_f3 col = rt_mk3(c4.x, c4.y, c4.z);
         if (h.leaf == RT_INVALID) {
@@ -477,22 +487,23 @@ __global__ __launch_bounds__(Q_THREADS) void k_shade(RtSceneView sv, RtBruteView
         rt[slot] = make_float4(col.x, col.y, col.z, 0.0f);
         alive = alive && (bounce + 1 < RT_MAX_BOUNCE);
         if (alive) {
-            po[slot] = make_float4(ray.origin.x, ray.origin.y, ray.origin.z, 0.0f);
-            pd[slot] = make_float4(ray.direction.x, ray.direction.y, ray.direction.z, 0.0f);
+            ray_record_store(rayIn, i, ray.origin, ray.direction, slot);   // in place; copied to its place in the next queue below
             pe[slot] = make_float4(ray.energy.x, ray.energy.y, ray.energy.z, 0.0f);
         }
     }
-    stage[it * Q_THREADS + threadIdx.x] = alive ? slot : RT_INVALID;
+    stage[it * Q_THREADS + threadIdx.x] = alive ? i : RT_INVALID;
     }
-    block_queue_flush(stage, queueOut, countOut);
+    block_queue_flush(stage, countOut, [&](uint32_t i, uint32_t at) {
+        rayOut[2 * (size_t)at] = rayIn[2 * (size_t)i];
+        rayOut[2 * (size_t)at + 1] = rayIn[2 * (size_t)i + 1];
+    });
 }
 
 // ------------------------------------------------------------------ ShadowMap pass (RayTracing.compute:96-131)
 // generate (primary ray, DoF-capable) -> traverse -> setup (hit point, disk
 // rotation) -> traverse 16 shadow rays per shaded pixel -> resolve.
-__global__ __launch_bounds__(Q_THREADS) void k_sm_setup(RtSceneView sv, RtTileMap tm, RtParams P, const uint32_t *__restrict__ queue,
-                                                   const uint32_t *__restrict__ qcount, const float4 *__restrict__ po,
-                                                   const float4 *__restrict__ pd, const uint2 *__restrict__ rng,
+__global__ __launch_bounds__(Q_THREADS) void k_sm_setup(RtSceneView sv, RtTileMap tm, RtParams P, const float4 *__restrict__ ray,
+                                                   const uint32_t *__restrict__ qcount, const uint2 *__restrict__ rng,
                                                    const RtHitRec *__restrict__ hitRec, float4 *__restrict__ rec,
                                                    float4 *__restrict__ shadowMap, uint32_t *__restrict__ smq,
                                                    uint32_t *__restrict__ smqCount, ShadowFrame frame, int skipUnshadowable,
@@ -507,15 +518,15 @@ __global__ __launch_bounds__(Q_THREADS) void k_sm_setup(RtSceneView sv, RtTileMa
     bool shaded = false, skipped = false;
     uint32_t slot = 0;
     if (i < n) {
-        slot = queue[i];
-        const RtHitRec h = hitRec[slot];
+        const float4 r0 = ray[2 * (size_t)i], r1 = ray[2 * (size_t)i + 1];
+        slot = __float_as_uint(r1.z);
+        const RtHitRec h = hitRec[i];
         if (h.leaf == RT_INVALID) {
             shadowMap[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
         } else {
-            const float4 o4 = po[slot], d4 = pd[slot];
             DHit hit;
             int castShadow;
-            load_hit(sv, h, rt_mk3(o4.x, o4.y, o4.z), rt_mk3(d4.x, d4.y, d4.z), hit, castShadow);
+            load_hit(sv, h, rt_mk3(r0.x, r0.y, r0.z), rt_mk3(r0.w, r1.x, r1.y), hit, castShadow);
             const rt_f3 origin = rt_add3(hit.position, rt_scale3(hit.normal, RT_NORMAL_BIAS));
             rt_rng r;
             uint32_t px, py;
@@ -556,7 +567,7 @@ __global__ __launch_bounds__(Q_THREADS) void k_sm_setup(RtSceneView sv, RtTileMa
         if ((threadIdx.x & 63u) == 0 && m) atomicAdd(shadowRayCounter, 16ull * (unsigned long long)__popcll(m));
     }
     }
-    block_queue_flush(stage, smq, smqCount);
+    block_queue_flush(stage, smqCount, [&](uint32_t shadedSlot, uint32_t at) { smq[at] = shadedSlot; });
 }
 
 // SoftShadow's running mean over the 16 rays, in ray order (Shadow.cginc:109-112).
@@ -707,13 +718,13 @@ RtSceneView rt_scene_view(RtContext *ctx)
 #define CNT_WORDS (24 * CNT_LINE)
 static_assert(2 * CNT_WORDS <= RT_COUNTER_BLOCK_WORDS, "counter block too small");   // one per stream
 #define RT_MAX_BATCH 64u
-#define RT_BATCH_PATH_SLOTS (1u << 27)   // frames in flight are chosen so that a launch covers up to this many paths (164 B each: 22 GB)
+#define RT_BATCH_PATH_SLOTS (1u << 27)   // frames in flight are chosen so that a launch covers up to this many paths (188 B each: 25 GB)
 
 void rt_free_render(RtContext *ctx)
 {
-    void **ptrs[] = {(void **)&ctx->dRt, (void **)&ctx->dConv, (void **)&ctx->dShadowMap, (void **)&ctx->dPo,
-                     (void **)&ctx->dPd, (void **)&ctx->dPe, (void **)&ctx->dRng, (void **)&ctx->dHit,
-                     (void **)&ctx->dQueue[0], (void **)&ctx->dQueue[1], (void **)&ctx->dSmQueue, (void **)&ctx->dSmRec,
+    void **ptrs[] = {(void **)&ctx->dRt, (void **)&ctx->dConv, (void **)&ctx->dShadowMap,
+                     (void **)&ctx->dPe, (void **)&ctx->dRng, (void **)&ctx->dHit,
+                     (void **)&ctx->dRay[0], (void **)&ctx->dRay[1], (void **)&ctx->dSmQueue, (void **)&ctx->dSmRec,
                      (void **)&ctx->dSmFlags, (void **)&ctx->dSeeds};
     for (void **p : ptrs) {
         if (*p) (void)hipFree(*p);
@@ -729,8 +740,8 @@ static int alloc_batch(RtContext *ctx, uint32_t frames)
     const uint32_t n = ctx->tile.nSlots;
     if (frames <= ctx->batchCap) return RT_OK;
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    void **ptrs[] = {(void **)&ctx->dRt, (void **)&ctx->dShadowMap, (void **)&ctx->dPo, (void **)&ctx->dPd, (void **)&ctx->dPe,
-                     (void **)&ctx->dRng, (void **)&ctx->dHit, (void **)&ctx->dQueue[0], (void **)&ctx->dQueue[1],
+    void **ptrs[] = {(void **)&ctx->dRt, (void **)&ctx->dShadowMap, (void **)&ctx->dPe,
+                     (void **)&ctx->dRng, (void **)&ctx->dHit, (void **)&ctx->dRay[0], (void **)&ctx->dRay[1],
                      (void **)&ctx->dSmQueue, (void **)&ctx->dSmRec, (void **)&ctx->dSmFlags, (void **)&ctx->dSeeds};
     for (void **p : ptrs) {
         if (*p) (void)hipFree(*p);
@@ -740,13 +751,11 @@ static int alloc_batch(RtContext *ctx, uint32_t frames)
     const size_t m = (size_t)(n ? n : 1) * frames;
     RT_HIP(ctx, hipMalloc((void **)&ctx->dRt, m * sizeof(float4)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dShadowMap, m * sizeof(float4)));
-    RT_HIP(ctx, hipMalloc((void **)&ctx->dPo, m * sizeof(float4)));
-    RT_HIP(ctx, hipMalloc((void **)&ctx->dPd, m * sizeof(float4)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dPe, m * sizeof(float4)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dRng, m * sizeof(uint2)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dHit, m * sizeof(RtHitRec)));
-    RT_HIP(ctx, hipMalloc((void **)&ctx->dQueue[0], m * sizeof(uint32_t)));
-    RT_HIP(ctx, hipMalloc((void **)&ctx->dQueue[1], m * sizeof(uint32_t)));
+    RT_HIP(ctx, hipMalloc((void **)&ctx->dRay[0], m * 2 * sizeof(float4)));
+    RT_HIP(ctx, hipMalloc((void **)&ctx->dRay[1], m * 2 * sizeof(float4)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dSmQueue, m * sizeof(uint32_t)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dSmRec, m * 2 * sizeof(float4)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dSmFlags, m * 16));
@@ -838,11 +847,11 @@ static bool shadow_shares_primary(const RtParams &P)
 
 static ShadowFrame shadow_frame(RtContext *ctx);
 
-static void launch_sm_setup(RtContext *ctx, const RtSceneView &sv, uint32_t total, const uint32_t *queue, const uint32_t *qcount)
+static void launch_sm_setup(RtContext *ctx, const RtSceneView &sv, uint32_t total, const float4 *ray, const uint32_t *qcount)
 {
     rt_timer_begin(ctx, "k_sm_setup");
-    hipLaunchKernelGGL(k_sm_setup, dim3((total + Q_TILE - 1) / Q_TILE), dim3(Q_THREADS), 0, ctx->stream, sv, ctx->tile, ctx->params, queue, qcount,
-                       ctx->dPo, ctx->dPd, ctx->dRng, ctx->dHit, ctx->dSmRec, ctx->dShadowMap, ctx->dSmQueue, ctx->dQCount + CNT_SMQ,
+    hipLaunchKernelGGL(k_sm_setup, dim3((total + Q_TILE - 1) / Q_TILE), dim3(Q_THREADS), 0, ctx->stream, sv, ctx->tile, ctx->params, ray, qcount,
+                       ctx->dRng, ctx->dHit, ctx->dSmRec, ctx->dShadowMap, ctx->dSmQueue, ctx->dQCount + CNT_SMQ,
                        shadow_frame(ctx), ctx->optCasterBox ? 1 : 0, ctx->countersOn ? ctx->dStats + 37 : nullptr);
     rt_timer_end(ctx);
 }
@@ -1046,15 +1055,13 @@ static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup
     RT_HIP(ctx, hipMemsetAsync(ctx->dQCount, 0, CNT_WORDS * sizeof(uint32_t), st));
     rt_timer_begin(ctx, "k_generate");
     hipLaunchKernelGGL((k_generate<RT_FLAG_DOF_PRIMARY, true>), grid, blk, 0, st, ctx->tile, ctx->params, ctx->dSeeds, frames,
-                       ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt, ctx->dRng, ctx->dQueue[0], ctx->dQCount);
+                       ctx->dRay[0], ctx->dPe, ctx->dRt, ctx->dRng, ctx->dQCount);
     rt_timer_end(ctx);
     for (int b = 0; b < RT_MAX_BOUNCE; ++b) {
-        uint32_t *qin = ctx->dQueue[b & 1], *qout = ctx->dQueue[(b + 1) & 1];
+        float4 *qin = ctx->dRay[b & 1], *qout = ctx->dRay[(b + 1) & 1];
         QueueSrc src;
-        src.queue = qin;
+        src.ray = qin;
         src.qcount = ctx->dQCount + CNT_Q(b);
-        src.po = ctx->dPo;
-        src.pd = ctx->dPd;
         src.hit = ctx->dHit;
         if (brute) {
             rt_timer_begin(ctx, "k_brute_extend");
@@ -1071,13 +1078,13 @@ static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup
         rt_timer_begin(ctx, "k_shade");
         if (brute)
             hipLaunchKernelGGL((k_shade<false, true>), grid, blk, 0, st, sv, ctx->brute, ctx->tile, ctx->params, b, qin, ctx->dQCount + CNT_Q(b), qout,
-                               ctx->dQCount + CNT_Q(b + 1), ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
+                               ctx->dQCount + CNT_Q(b + 1), ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
         else if (ctx->optMaterialSort)
             hipLaunchKernelGGL((k_shade<true, false>), grid, blk, 0, st, sv, ctx->brute, ctx->tile, ctx->params, b, qin, ctx->dQCount + CNT_Q(b), qout,
-                               ctx->dQCount + CNT_Q(b + 1), ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
+                               ctx->dQCount + CNT_Q(b + 1), ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
         else
             hipLaunchKernelGGL((k_shade<false, false>), grid, blk, 0, st, sv, ctx->brute, ctx->tile, ctx->params, b, qin, ctx->dQCount + CNT_Q(b), qout,
-                               ctx->dQCount + CNT_Q(b + 1), ctx->dPo, ctx->dPd, ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
+                               ctx->dQCount + CNT_Q(b + 1), ctx->dPe, ctx->dRt, ctx->dRng, ctx->dHit);
         rt_timer_end(ctx);
     }
     ctx->lastFrame = frames - 1;
@@ -1099,17 +1106,15 @@ static int shadowmap_frames(RtContext *ctx, uint32_t frames)
     RT_HIP(ctx, hipMemsetAsync(cnt + CNT_FETCH_SM0, 0, 2 * CNT_LINE * sizeof(uint32_t), st));    // both ShadowMap cursors
     rt_timer_begin(ctx, "k_sm_generate");
     hipLaunchKernelGGL((k_generate<RT_FLAG_DEPTH_OF_FIELD, false>), dim3((total + Q_TILE - 1) / Q_TILE), dim3(Q_THREADS), 0, st, ctx->tile, ctx->params,
-                       ctx->dSeeds, frames, ctx->dPo, ctx->dPd, ctx->dPe, ctx->dShadowMap, ctx->dRng, ctx->dQueue[0], cnt + CNT_SMPRIM);
+                       ctx->dSeeds, frames, ctx->dRay[0], ctx->dPe, ctx->dShadowMap, ctx->dRng, cnt + CNT_SMPRIM);
     rt_timer_end(ctx);
     QueueSrc prim;
-    prim.queue = ctx->dQueue[0];
+    prim.ray = ctx->dRay[0];
     prim.qcount = cnt + CNT_SMPRIM;
-    prim.po = ctx->dPo;
-    prim.pd = ctx->dPd;
     prim.hit = ctx->dHit;
     if (ctx->optPacketPrimary) launch_traverse_packets(ctx, sv, prim, cnt + CNT_FETCH_SM0, total, "k_extend");
     else launch_traverse(ctx, sv, prim, cnt + CNT_FETCH_SM0, total, "k_extend");
-    launch_sm_setup(ctx, sv, total, ctx->dQueue[0], cnt + CNT_SMPRIM);
+    launch_sm_setup(ctx, sv, total, ctx->dRay[0], cnt + CNT_SMPRIM);
     launch_shadow_rays(ctx, sv, total);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
@@ -1159,20 +1164,20 @@ int rt_accumulate_impl(RtContext *ctx, uint32_t samplePerPixel, int useShadowMap
 struct RtLaneScope {
     RtContext *ctx;
     hipStream_t stream;
-    float4 *rt, *sm, *po, *pd, *pe, *smRec;
+    float4 *rt, *sm, *pe, *smRec, *ray0, *ray1;
     uint2 *rng;
     RtHitRec *hit;
-    uint32_t *q0, *q1, *smq, *cnt;
+    uint32_t *smq, *cnt;
     uint8_t *smFlags;
     float *seeds;
     RtLaneScope(RtContext *c, hipStream_t s, uint32_t firstFrame, uint32_t *counters)
-        : ctx(c), stream(c->stream), rt(c->dRt), sm(c->dShadowMap), po(c->dPo), pd(c->dPd), pe(c->dPe), smRec(c->dSmRec), rng(c->dRng),
-          hit(c->dHit), q0(c->dQueue[0]), q1(c->dQueue[1]), smq(c->dSmQueue), cnt(c->dQCount), smFlags(c->dSmFlags), seeds(c->dSeeds)
+        : ctx(c), stream(c->stream), rt(c->dRt), sm(c->dShadowMap), pe(c->dPe), smRec(c->dSmRec), ray0(c->dRay[0]), ray1(c->dRay[1]), rng(c->dRng),
+          hit(c->dHit), smq(c->dSmQueue), cnt(c->dQCount), smFlags(c->dSmFlags), seeds(c->dSeeds)
     {
         const size_t off = (size_t)firstFrame * c->tile.nSlots;
         c->stream = s;
-        c->dRt += off; c->dShadowMap += off; c->dPo += off; c->dPd += off; c->dPe += off; c->dRng += off; c->dHit += off;
-        c->dQueue[0] += off; c->dQueue[1] += off; c->dSmQueue += off; c->dSmRec += 2 * off; c->dSmFlags += 16 * off;
+        c->dRt += off; c->dShadowMap += off; c->dPe += off; c->dRng += off; c->dHit += off;
+        c->dRay[0] += 2 * off; c->dRay[1] += 2 * off; c->dSmQueue += off; c->dSmRec += 2 * off; c->dSmFlags += 16 * off;
         c->dSeeds += firstFrame;
         c->dQCount = counters;
         c->spillArea = 1;        // the overlapped shadow launch, the other user of area 1, is off with two streams
@@ -1181,8 +1186,8 @@ struct RtLaneScope {
     {
         RtContext *c = ctx;
         c->stream = stream;
-        c->dRt = rt; c->dShadowMap = sm; c->dPo = po; c->dPd = pd; c->dPe = pe; c->dSmRec = smRec; c->dRng = rng; c->dHit = hit;
-        c->dQueue[0] = q0; c->dQueue[1] = q1; c->dSmQueue = smq; c->dQCount = cnt; c->dSmFlags = smFlags; c->dSeeds = seeds;
+        c->dRt = rt; c->dShadowMap = sm; c->dPe = pe; c->dSmRec = smRec; c->dRng = rng; c->dHit = hit;
+        c->dRay[0] = ray0; c->dRay[1] = ray1; c->dSmQueue = smq; c->dQCount = cnt; c->dSmFlags = smFlags; c->dSeeds = seeds;
         c->spillArea = 0;
     }
 };

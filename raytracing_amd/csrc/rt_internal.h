@@ -196,10 +196,10 @@ struct RtContext {
     RtTileMap tile;
     uint32_t allocSlots = 0;
     float4 *dRt = nullptr, *dConv = nullptr, *dShadowMap = nullptr;
-    float4 *dPo = nullptr, *dPd = nullptr, *dPe = nullptr;
+    float4 *dPe = nullptr;                // path energy, by path slot
+    float4 *dRay[2] = {nullptr, nullptr}; // the ray queues of a bounce and the next: 2 x float4 per entry, in queue order (render.hip)
     uint2 *dRng = nullptr;
     RtHitRec *dHit = nullptr;
-    uint32_t *dQueue[2] = {nullptr, nullptr};
     uint32_t *dQCount = nullptr;          // 32-word counter block, owned by the context
     uint32_t *dSmQueue = nullptr;         // ShadowMap pass: shaded path slots
     float *dSeeds = nullptr;              // per-frame seeds of the batch in flight
