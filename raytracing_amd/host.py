@@ -143,6 +143,47 @@ class BVH:
             self.onDirty()                       # RayTracing.SetDirty() (BVH.cs:351)
 
 
+class CustomMaterialInfo:
+    """CustomMaterialInfo.cs:6-103: the six material presets of the PBR sphere row (README pbr0..pbr5).
+    `renderers` = parent.GetComponentsInChildren<Renderer>(): objects named Sphere_<k>, whose ratio is k / 5."""
+
+    def __init__(self, bvh: "BVH", renderers: List["MeshRenderer"]):
+        self.bvh = bvh
+        self.materials = [r.sharedMaterial for r in renderers]                       # :17
+        self.ratios = [float(r.name.split("_")[1]) / 5.0 for r in renderers]          # :18
+
+    def OnMaterialChanged(self, index: int):                                           # :21-76
+        n, ratios = len(self.materials), self.ratios
+        metallic, smoothness, transparent, ior, material_type = [0.0] * n, [0.0] * n, [0.0] * n, [0.0] * n, 0
+        if index == 0:
+            metallic, smoothness, transparent, ior, material_type = [0.0] * n, ratios, [-1.0] * n, [1.0] * n, 0
+        elif index == 1:
+            metallic, smoothness, transparent, ior, material_type = [1.0] * n, ratios, [-1.0] * n, [1.0] * n, 0
+        elif index == 2:
+            metallic, smoothness, transparent, ior, material_type = [0.0] * n, ratios, [0.1] * n, [1.1] * n, 1
+        elif index == 3:
+            metallic, smoothness, transparent, ior, material_type = [0.0] * n, [1.0] * n, [0.1] * n, [1.0 + v * 0.5 for v in ratios], 1
+        elif index == 4:
+            metallic, smoothness, transparent, ior, material_type = [1.0] * n, [1.0] * n, [-1.0] * n, [1.0 + v * 0.5 for v in ratios], 3
+        elif index == 5:
+            metallic, smoothness, transparent, ior, material_type = [0.0] * n, [1.0] * n, ratios, [1.1] * n, 1
+        self.ChangeMaterial(metallic, smoothness, transparent, ior, material_type)
+
+    def ChangeMaterial(self, metallic, smoothness, transparent, ior, material_type):  # :78-102
+        for i, mat in enumerate(self.materials):
+            mat._Metallic = max(0.01, metallic[i])
+            mat._Glossiness = max(0.01, smoothness[i])
+            mat._IOR = ior[i]
+            mat._MaterialType = material_type
+            if material_type == 1:
+                mat._Mode = 3
+                mat.color = (mat.color[0], mat.color[1], mat.color[2], transparent[i])
+            else:
+                mat._Mode = 0
+        if self.bvh.core is not None:
+            self.bvh.UpdateMaterialData()
+
+
 # ------------------------------------------------------------------ MeshCollector.cs
 class MeshCollector:
     """MeshCollector.cs: the brute-force primitive lists of chapters 2-4 (useBVH = false).

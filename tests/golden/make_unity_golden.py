@@ -14,6 +14,10 @@
   unity_chapter7_5_1_scene.npz, reference_bloom1_blocks.npy
                                Assets/Scenes/Chapter7_5_1.unity with the parameters of its Bloom component, and bloom1.png,
                                the image published of it with that post-process stage on
+  unity_chapter6_5_scene.npz, reference_pbr_blocks.npy
+                               Assets/Scenes/Chapter6_5.unity (six spheres over a checker floor) with the material table of each
+                               of the six presets of CustomMaterialInfo.cs:30-74 (`materials_preset` [6, n]), and the block
+                               means of pbr0.png .. pbr5.png, the images published of those presets
   unity_chapter3_4_primitives.npz, unity_chapter4_1_primitives.npz
                                the buffers MeshCollector.Init would upload for two scenes that run with useBVH = false
                                (planes / spheres / cubes; Chapter4_1 adds five custom meshes, 13444 triangles),
@@ -73,6 +77,36 @@ for name, scene in (("MIS", "Chapter6_4"), ("LightSampling", "Chapter6_2")):
 b, w, h = blocks_of("bloom1.png")
 np.save(os.path.join(HERE, "reference_bloom1_blocks.npy"), b)
 export("Chapter7_5_1.unity", "unity_chapter7_5_1_scene.npz", w, h, with_bloom=True)
+
+
+# Chapter6_5: the PBR row.  CustomMaterialInfo.OnMaterialChanged(k) rewrites the six spheres' materials; pbr<k>.png is preset k.
+from raytracing_amd import host  # noqa: E402
+
+blocks = []
+for k in range(6):
+    b, w, h = blocks_of(f"pbr{k}.png")
+    blocks.append(b)
+np.save(os.path.join(HERE, "reference_pbr_blocks.npy"), np.stack(blocks))
+ls = unity.load_scene(os.path.join(root, "Assets/Scenes", "Chapter6_5.unity"), root, w, h)
+rt = ls.rayTracing
+(v, i, mi, sh), mats = rt.bvh.InitMesh()
+spheres = [mr for mr in rt.bvh.meshParent if mr.enabled and mr.activeInHierarchy and mr.name.startswith("Sphere_")]
+assert sorted(mr.name for mr in spheres) == [f"Sphere_{k}" for k in range(6)]
+info = host.CustomMaterialInfo(rt.bvh, spheres)
+presets = []
+for k in range(6):
+    info.OnMaterialChanged(k)
+    presets.append(np.array([m.MaterialData() for m in mats], wire.MATERIAL))
+sph, area, disc = rt.lightImportanceSampling.Lights()
+np.savez_compressed(os.path.join(HERE, "unity_chapter6_5_scene.npz"), vertices=v, indices=i, material_index=mi, shadow_index=sh,
+                    materials_preset=np.stack(presets), sphere_lights=sph, area_lights=area, disc_lights=disc,
+                    params=np.frombuffer(bytes(rt.BuildParameters()), np.uint8))
+print(f"Chapter6_5.unity: {len(mi)} triangles, {len(mats)} materials x 6 presets, {len(sph)}/{len(area)}/{len(disc)} lights")
+
+# UniformSampling.png and CosineSampling.png were rendered from a scene state that is not in the checkout: neither
+# Chapter6_1.unity (samplingType 0) nor Chapter6_2.unity with the sampling type switched reproduces them -- their light is
+# smaller and about a third brighter (block means 16 - 24 counts apart, correlation 0.80 - 0.93, against 2.5 - 3.9 counts
+# for the three images above) -- so they are not used as anchors.
 
 
 def export_primitives(scene, out, w, h):

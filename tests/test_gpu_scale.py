@@ -348,6 +348,53 @@ def test_reference_scene_reproduces_the_published_image(core, scene, image, medi
         assert walls.mean() <= 3 and (walls <= 8).mean() >= 0.98
 
 
+def _block_difference(core, sc, p, want, frames=512):
+    from raytracing_amd.ingest import png
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(p)
+    core.set_dirty()
+    core.render_frames(scenes.frame_seeds(frames, 1))
+    got = png.linear_to_srgb8(core.readback(wire.IMAGE_CONVERGED)[::-1, :, :3]).astype(np.float64)
+    k = 16
+    g = got[:want.shape[0] * k, :want.shape[1] * k].reshape(want.shape[0], k, want.shape[1], k, 3).mean((1, 3))
+    return np.abs(g - want).max(-1), g
+
+
+@pytest.mark.parametrize("preset", range(6))
+def test_pbr_presets_reproduce_the_published_images(core, preset):
+    """Assets/Scenes/Chapter6_5.unity, the row of six spheres, with the material table that preset `preset` of
+    CustomMaterialInfo.cs:30-74 leaves (metallic / smoothness / transparency / IOR sweeps, clear coat), against
+    pbr<preset>.png, the image the reference's author published of that preset: 16 x 16 block means of the 8-bit
+    sRGB values.  The published HDRI -- a street photograph that fills the upper half of the frame and lights the
+    scene -- is absent from the checkout (a procedural sky stands in), so the comparison covers what does not show
+    the sky: the floor with the six shadows, and for the opaque presets the bodies of the spheres; and since the
+    sky also sets level and tint of the light, one gain per colour channel is fitted first.  What is left after
+    that -- geometry, camera, shadows, the shading of each material class -- agrees to a few counts."""
+    import os
+    golden = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(golden, "unity_chapter6_5_scene.npz"))
+    want = np.load(os.path.join(golden, "reference_pbr_blocks.npy"))[preset].astype(np.float64)
+    p = wire.RtParams.from_buffer_copy(z["params"].tobytes())
+    sc = scenes.Scene("chapter6_5", z["vertices"], z["indices"], z["material_index"], z["shadow_index"], z["materials_preset"][preset],
+                      z["sphere_lights"], z["area_lights"], z["disc_lights"], scenes.procedural_skybox(64), p)
+    _, g = _block_difference(core, sc, p, want)
+    mask = np.zeros(g.shape[:2], bool)
+    mask[33:47] = True                                           # the floor in front of the spheres, shadows included
+    opaque = preset in (0, 1, 4)
+    if opaque:
+        for c0, c1 in ((6, 13), (18, 24), (29, 35), (41, 46), (52, 57), (63, 69)):
+            mask[22:28, c0:c1] = True                            # the inside of each sphere's outline
+    G, W = g[mask], want[mask]
+    gain = (G * W).sum(0) / (G * G).sum(0)
+    res = np.abs(G * gain - W).max(-1)
+    corr = np.corrcoef(G.mean(-1), W.mean(-1))[0, 1]
+    print(f"\nchapter6_5 preset {preset} vs published pbr{preset}: gain {np.round(gain, 3)}, residual median {np.median(res):.2f}/255, "
+          f"{100 * (res <= 8).mean():.0f}% within 8, correlation {corr:.4f}")
+    assert (gain > 0.8).all() and (gain < 1.2).all()
+    assert np.median(res) <= 4.0 and (res <= 8).mean() >= 0.80 and corr >= 0.98
+
+
 def test_published_image_with_the_bloom_stage(core):
     """Assets/Scenes/Chapter7_5_1.unity (a teapot behind pillars in front of a long emissive quad) and bloom1.png, the
     image published of it WITH the scene's bloom stage on (threshold 0.001, 7 steps, sigma 0.05, intensity 0.02; the
