@@ -16,6 +16,7 @@ public static class RtCoreNative
     const string Lib = "rtcore";
 
     public const int RT_OK = 0, RT_E_INVALID = -1, RT_E_DEVICE = -2, RT_E_NOMEM = -3, RT_E_STATE = -4, RT_E_OVERFLOW = -5;
+    public const uint RT_TRACE_STATIC_MAX_RAYS = 1u << 24;
     public const uint RT_FLAG_DEPTH_OF_FIELD = 0x10, RT_FLAG_DOF_PRIMARY = 0x20, RT_FLAG_MATTE_MASK = 0x40, RT_FLAG_BRUTE_FORCE = 0x80;
     public const int RT_IMAGE_RT = 0, RT_IMAGE_CONVERGED = 1, RT_IMAGE_SHADOWMAP = 2, RT_IMAGE_POSTPROCESS = 3, RT_IMAGE_USER = 4;
     public const int RT_WRAP_CLAMP = 0, RT_WRAP_REPEAT = 1;
@@ -48,10 +49,11 @@ public static class RtCoreNative
     }
 
     [StructLayout(LayoutKind.Sequential)]
-    public struct RtStats
+    public struct RtStats                            // 17 eight-byte fields, 136 B
     {
         public ulong rays, internalVisits, leafVisits, triTests, hits, paths; public double buildMs, renderMs;
         public ulong shadowRays, shadowInternalVisits, shadowLeafVisits, shadowTriTests, shadowHits;
+        public ulong raysWalked, shadowRaysWalked;   // rays / shadowRays count every ray ANSWERED; these two only the ones a tree walk answered
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -63,19 +65,66 @@ public static class RtCoreNative
         public int wrapMode;
     }
 
+    // Brute-force primitive records (useBVH = false).  Field for field the private nested structs of
+    // MeshCollector (MeshCollector.cs:47-156: normal/position/size, center/radius, min/max, matrix/offset/count,
+    // each followed by the Primitive block albedo, metallic, smoothness, transparent, emissionColor); the host
+    // either makes those internal and passes its own arrays, or fills these.
+    [StructLayout(LayoutKind.Sequential)]
+    public struct Plane                                                                                 // 72 B
+    {
+        public Vector3 normal, position, size;
+        public Vector3 albedo; public float metallic, smoothness, transparent; public Vector3 emissionColor;
+    }
+    [StructLayout(LayoutKind.Sequential)]
+    public struct Sphere                                                                                // 52 B
+    {
+        public Vector3 center; public float radius;
+        public Vector3 albedo; public float metallic, smoothness, transparent; public Vector3 emissionColor;
+    }
+    [StructLayout(LayoutKind.Sequential)]
+    public struct Cube                                                                                  // 60 B
+    {
+        public Vector3 min, max;
+        public Vector3 albedo; public float metallic, smoothness, transparent; public Vector3 emissionColor;
+    }
+    [StructLayout(LayoutKind.Sequential)]
+    public struct CustomMesh                                                                            // 108 B
+    {
+        public Matrix4x4 localToWorldMatrix; public int indicesOffset, indicesCount;
+        public Vector3 albedo; public float metallic, smoothness, transparent; public Vector3 emissionColor;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct RtHit { public float t, u, v; public uint triangle; }                                // 16 B, rt_trace_rays_device*
+
+    // ---- context
     [DllImport(Lib)] public static extern int rt_create(int deviceId, out IntPtr ctx);
     [DllImport(Lib)] public static extern int rt_destroy(IntPtr ctx);
     [DllImport(Lib)] public static extern IntPtr rt_last_error(IntPtr ctx);
+    [DllImport(Lib)] public static extern IntPtr rt_version();
+    [DllImport(Lib)] public static extern int rt_synchronize(IntPtr ctx);
+
+    // ---- scene (BVH.Init, LightImportanceSampling.Init, RayTracing.InitShader)
     [DllImport(Lib)] public static extern int rt_scene_upload(IntPtr ctx, MeshVertex[] vertices, uint nVertices, uint[] indices, uint nIndices,
                                                                uint[] materialIndex, Vector2Int[] shadowIndex, uint nTriangles);
     [DllImport(Lib)] public static extern int rt_materials_upload(IntPtr ctx, MaterialData[] materials, uint n);
     [DllImport(Lib)] public static extern int rt_lights_upload(IntPtr ctx, SphereLight[] sphere, uint nSphere, AreaLight[] area, uint nArea,
                                                                 DiscLight[] disc, uint nDisc);
     [DllImport(Lib)] public static extern int rt_skybox_upload(IntPtr ctx, float[] facesRgba, uint size);
+    [DllImport(Lib)] public static extern int rt_primitives_upload(IntPtr ctx, Plane[] planes, uint nPlanes, Sphere[] spheres, uint nSpheres, Cube[] cubes, uint nCubes,
+                                                                   CustomMesh[] customMeshes, uint nMeshes, Vector3[] vertices, Vector3[] normals, uint nVertices,
+                                                                   int[] indices, uint nIndices);
+    [DllImport(Lib)] public static extern int rt_trace_primitives(IntPtr ctx, Vector3[] origins, Vector3[] directions, uint n, float[] outT, uint[] outPrimitive,
+                                                                  Vector3[] outNormal);
+
+    // ---- BVH (BVH.Build and the buffers BVH.cs:133-160 binds)
     [DllImport(Lib)] public static extern int rt_bvh_build(IntPtr ctx);
     [DllImport(Lib)] public static extern int rt_readback_bvh(IntPtr ctx, uint[] morton, uint[] sortedIndex, AABB[] triangleAabb, Triangle[] triangles,
                                                                InternalNode[] internalNodes, LeafNode[] leafNodes, AABB[] bvhData);
+    [DllImport(Lib)] public static extern int rt_readback_sort_stages(IntPtr ctx, uint[] mortonUnsorted, uint[] mortonSortedRaw);
     [DllImport(Lib)] public static extern int rt_readback_walk_tree(IntPtr ctx, uint[] nodes8, uint[] leafTriangle, uint[] leafRank);
+
+    // ---- render (RayTracing.CustomRender)
     [DllImport(Lib)] public static extern int rt_set_params(IntPtr ctx, ref RtParams p);
     [DllImport(Lib)] public static extern int rt_dispatch(IntPtr ctx);
     [DllImport(Lib)] public static extern int rt_dispatch_shadowmap(IntPtr ctx);
@@ -85,20 +134,36 @@ public static class RtCoreNative
     [DllImport(Lib)] public static extern uint rt_sample_count(IntPtr ctx);
     [DllImport(Lib)] public static extern int rt_readback(IntPtr ctx, int which, Color[] dstRgba);     // Color = 4 floats
     [DllImport(Lib)] public static extern int rt_upload_converged(IntPtr ctx, Color[] srcRgba, uint samplePerPixel);
-    [DllImport(Lib)] public static extern int rt_get_stats(IntPtr ctx, out RtStats stats);
+
+    // ---- one frame split over several GPUs: one context per device, RtParams.tileRank = 0..tileCount-1.
+    // In one process: render every context (a thread each), then rt_readback_merge each into ONE Color[width*height].
+    // One process per GPU: rt_readback_local_device into a device buffer that the process group gathers;
+    // rt_local_pixel_map says which pixel each tile-local slot is.
+    [DllImport(Lib)] public static extern int rt_readback_merge(IntPtr ctx, int which, Color[] frameRgba);
+    [DllImport(Lib)] public static extern int rt_readback_local_device(IntPtr ctx, int which, IntPtr deviceDst);
+    [DllImport(Lib)] public static extern uint rt_local_pixel_count(IntPtr ctx);
+    [DllImport(Lib)] public static extern int rt_local_pixel_map(IntPtr ctx, uint[] dst);
+
+    // ---- bare ray queries (Tracing.cginc BVHRayTrace without shading)
+    [DllImport(Lib)] public static extern int rt_trace_rays(IntPtr ctx, Vector3[] origins, Vector3[] directions, uint n, float[] outT, uint[] outTriangle,
+                                                            float[] outU, float[] outV);
+    [DllImport(Lib)] public static extern int rt_trace_rays_device(IntPtr ctx, IntPtr deviceOrigins4, IntPtr deviceDirs4, uint n, IntPtr deviceHits4);
+    // the same, for callers that must not allocate device memory (n <= RT_TRACE_STATIC_MAX_RAYS; calls on one GPU must not overlap)
+    [DllImport(Lib)] public static extern int rt_trace_rays_device_static(IntPtr ctx, IntPtr deviceOrigins4, IntPtr deviceDirs4, uint n, IntPtr deviceHits4);
+
+    // ---- options, counters, timing
     [DllImport(Lib)] public static extern int rt_set_option(IntPtr ctx, int option, int value);
     public const int RT_OPT_PACKET_SHADOW = 0, RT_OPT_PACKET_PRIMARY = 1, RT_OPT_PACKET_TRACE = 2, RT_OPT_BATCH_FRAMES = 3,
                      RT_OPT_MATERIAL_SORT = 4, RT_OPT_TWO_STREAMS = 5, RT_OPT_OVERLAP_SHADOW = 6, RT_OPT_OVERLAP_AFTER = 7,
                      RT_OPT_OVERLAP_CUS = 8, RT_OPT_FIRST_HIT_SHADOW = 9, RT_OPT_CASTER_BOX = 10;
+    [DllImport(Lib)] public static extern int rt_enable_counters(IntPtr ctx, int enable);
+    [DllImport(Lib)] public static extern int rt_enable_kernel_timing(IntPtr ctx, int enable);
+    [DllImport(Lib)] public static extern int rt_reset_stats(IntPtr ctx);
+    [DllImport(Lib)] public static extern int rt_get_stats(IntPtr ctx, out RtStats stats);
+    [DllImport(Lib, CharSet = CharSet.Ansi)] public static extern int rt_kernel_time(IntPtr ctx, string kernelName, out double totalMs, out ulong launches);
+    [DllImport(Lib)] public static extern int rt_debug_eval(IntPtr ctx, int which, float[] x, float[] y, uint n, float[] result);
 
-    // brute-force primitives (useBVH = false): T = the host's own Plane / Sphere / Cube / CustomMesh structs (MeshCollector.cs:46-156)
-    [DllImport(Lib)] public static extern int rt_primitives_upload(IntPtr ctx, Array planes, uint nPlanes, Array spheres, uint nSpheres, Array cubes, uint nCubes,
-                                                                   Array customMeshes, uint nMeshes, Vector3[] vertices, Vector3[] normals, uint nVertices,
-                                                                   int[] indices, uint nIndices);
-    [DllImport(Lib)] public static extern int rt_trace_primitives(IntPtr ctx, Vector3[] origins, Vector3[] directions, uint n, float[] outT, uint[] outPrimitive,
-                                                                  Vector3[] outNormal);
-
-    // post-process chain: the destination is always RT_IMAGE_POSTPROCESS (RayTracing.postProcessRT)
+    // ---- post-process chain: the destination is always RT_IMAGE_POSTPROCESS (RayTracing.postProcessRT)
     [DllImport(Lib)] public static extern int rt_image_upload(IntPtr ctx, Color[] rgba, int width, int height);
     [DllImport(Lib)] public static extern int rt_image_size(IntPtr ctx, int which, out int width, out int height);
     [DllImport(Lib)] public static extern int rt_post_blit(IntPtr ctx, int src);
@@ -111,5 +176,22 @@ public static class RtCoreNative
     public static void Check(IntPtr ctx, int rc)
     {
         if (rc != RT_OK) Debug.LogError("rtcore error " + rc + ": " + Marshal.PtrToStringAnsi(rt_last_error(ctx)));
+    }
+
+    // One frame over several GPUs from one process: `contexts[i]` lives on device i and has been given
+    // RtParams.tileRank = i, tileCount = contexts.Length.  Each context renders on a thread of its own;
+    // the tiles are then merged into `frame` (width*height Colors, row 0 = bottom).
+    public static void RenderSplitFrame(IntPtr[] contexts, float[] seeds, Color[] frame)
+    {
+        var threads = new System.Threading.Thread[contexts.Length];
+        var codes = new int[contexts.Length];
+        for (int i = 0; i < contexts.Length; ++i)
+        {
+            int k = i;
+            threads[k] = new System.Threading.Thread(() => { codes[k] = rt_render_frames(contexts[k], seeds, (uint)seeds.Length); });
+            threads[k].Start();
+        }
+        for (int i = 0; i < contexts.Length; ++i) { threads[i].Join(); Check(contexts[i], codes[i]); }
+        for (int i = 0; i < contexts.Length; ++i) Check(contexts[i], rt_readback_merge(contexts[i], RT_IMAGE_CONVERGED, frame));
     }
 }

@@ -277,6 +277,14 @@ uint32_t rt_sample_count(RtContext *ctx);
  * of tiles owned by other ranks read 0.  RT_IMAGE_POSTPROCESS / RT_IMAGE_USER
  * have the size of the frame they were made from (rt_image_size). */
 int rt_readback(RtContext *ctx, int which, float *dst_rgba);
+/* The same image written INTO a full frame the caller already holds: only the
+ * pixels of this context's tiles are stored, every other pixel keeps its
+ * value.  A host that drives several GPUs from one process (one context per
+ * device, RtParams.tileRank = 0..tileCount-1) calls it once per context on one
+ * buffer and ends up with the frame RayTracing.cs:365-370 blits; the contexts
+ * write disjoint pixels, so the calls may run from different threads.
+ * RT_IMAGE_RT / RT_IMAGE_CONVERGED / RT_IMAGE_SHADOWMAP only. */
+int rt_readback_merge(RtContext *ctx, int which, float *frame_rgba);
 /* Same image, but only this rank's tiles in tile-local order, copied to a
  * DEVICE pointer (e.g. a torch tensor) of rt_local_pixel_count()*4 floats, for
  * gathering over RCCL without a host hop. */

@@ -438,12 +438,30 @@ int rt_readback(RtContext *ctx, int which, float *dst_rgba)
     const size_t px = (size_t)ctx->params.width * ctx->params.height;
     float4 *full = nullptr;
     RT_HIP(ctx, hipMalloc((void **)&full, px * sizeof(float4)));
+    struct Release { float4 *p; ~Release() { (void)hipFree(p); } } release{full};      // also on the early returns below
     RT_HIP(ctx, hipMemsetAsync(full, 0, px * sizeof(float4), ctx->stream));
     int rc = rt_expand_local_impl(ctx, src, full);
     if (rc) return rc;
     RT_HIP(ctx, hipMemcpyAsync(dst_rgba, full, px * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(full);
+    rt_timer_resolve(ctx);
+    return check_error_flag(ctx);
+}
+
+int rt_readback_merge(RtContext *ctx, int which, float *frame_rgba)
+{
+    RT_ENTER(ctx);
+    if (!ctx->paramsSet) return rt_fail(ctx, RT_E_STATE, "rt_set_params has not been called");
+    float4 *src = rt_image_ptr(ctx, which);
+    if (!src || !frame_rgba) return rt_fail(ctx, RT_E_INVALID, "bad image selector or null destination");
+    const uint32_t n = ctx->tile.nSlots;
+    std::vector<float> local((size_t)n * 4);
+    RT_HIP(ctx, hipMemcpyAsync(local.data(), src, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t s = 0; s < n; ++s) {          // only this context's pixels are written: contexts that split one frame merge into one buffer
+        uint32_t px, py;
+        if (ctx->tile.slot_to_pixel(s, &px, &py)) memcpy(frame_rgba + ((size_t)py * ctx->params.width + px) * 4, &local[(size_t)s * 4], 16);
+    }
     rt_timer_resolve(ctx);
     return check_error_flag(ctx);
 }

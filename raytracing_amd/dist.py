@@ -24,6 +24,8 @@ PAD = 0xFFFFFFFF
 
 def broadcast_scene(sc, device, src=0):
     """Every rank returns the same scenes.Scene; only `src` needs to pass one."""
+    if sc is not None and sc.primitives is not None:
+        raise ValueError("broadcast_scene: the brute-force primitive lists are not sharded; trace them on one rank")
     rank = dist.get_rank()
     meta = [None]
     if rank == src:
@@ -79,39 +81,67 @@ def tile_pixel_map(width, height, tile_size, rank, world):
 
 
 class TileGatherer:
-    """Gathers every rank's tile-local float4 image on rank 0 and scatters it
-    into the full frame.  Point-to-point fan-in (dist.gather): each peer has its
-    own xGMI link to the root, so all transfers run concurrently; no ring."""
+    """Gathers every rank's tile-local float4 image on rank 0 and places it in
+    the full frame.  Point-to-point fan-in (dist.gather): each peer has its own
+    xGMI link to the root, so all transfers run concurrently; no ring.
 
-    def __init__(self, width, height, tile_size, device, dst=0):
-        self.rank, self.world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    Every pixel belongs to exactly one rank, so the placement is a permutation
+    known when the gatherer is made: `source[p]` is the slot of pixel p in the
+    stacked receive buffer, and one index_select per image writes the frame in
+    pixel order (no mask, no device-side count, no host synchronisation)."""
+
+    def __init__(self, width, height, tile_size, device, dst=0, contexts=None):
+        """`contexts` = n makes a gatherer for n contexts driven from THIS process
+        (one per GPU, tileRank 0..n-1): no process group is touched and the images
+        are handed to place() instead of gather()."""
+        if contexts is not None:
+            self.rank, self.world, dst = 0, int(contexts), 0
+        else:
+            self.rank, self.world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+        self.in_process = contexts is not None
         self.dst, self.device = dst, device
-        self.width, self.height = width, height
+        self.width, self.height, self.tile_size = width, height, tile_size
         maps = [tile_pixel_map(width, height, tile_size, r, self.world) for r in range(self.world)]
         self.n_local = len(maps[self.rank])
         self.max_local = max(len(m) for m in maps)
         self.send = torch.zeros(self.max_local * 4, dtype=torch.float32, device=device)
+        self.stacked, self.recv, self.source, self.frame = None, None, None, None
         if self.rank == dst:
-            self.maps = [torch.from_numpy(m).to(device) for m in maps]
-            self.recv = [torch.zeros(self.max_local * 4, dtype=torch.float32, device=device) for _ in range(self.world)]
+            source = np.full(width * height, -1, np.int64)
+            for r, m in enumerate(maps):
+                slots = np.nonzero(m != PAD)[0]
+                source[m[slots]] = r * self.max_local + slots
+            if (source < 0).any():
+                raise AssertionError("tile maps do not cover the frame")
+            self.source = torch.from_numpy(source).to(device)
+            if self.world > 1:
+                self.stacked = torch.zeros(self.world, self.max_local * 4, dtype=torch.float32, device=device)
+                self.recv = list(self.stacked.unbind(0))        # contiguous rows: the gather list aliases `stacked`
+            else:
+                self.stacked = self.send.view(1, -1)
             self.frame = torch.zeros(width * height, 4, dtype=torch.float32, device=device)
-        else:
-            self.maps, self.recv, self.frame = None, None, None
 
     def local_buffer(self):
         """Flat float32 view (n_local*4) to be filled with this rank's tile-local image."""
         return self.send[: self.n_local * 4]
 
+    def rank_buffer(self, rank):
+        """In-process use: the flat float32 view context `rank` copies its tile-local image into."""
+        n = len(tile_pixel_map(self.width, self.height, self.tile_size, rank, self.world))
+        return self.stacked[rank, : n * 4]
+
+    def place(self):
+        """In-process use: the (height, width, 4) frame made of what the contexts wrote into their rank_buffer()s."""
+        torch.index_select(self.stacked.view(-1, 4), 0, self.source, out=self.frame)
+        return self.frame.view(self.height, self.width, 4)
+
     def gather(self):
         """Collective.  Returns the (height, width, 4) frame on the destination rank, None elsewhere."""
+        if self.in_process:
+            raise RuntimeError("this gatherer serves contexts of one process: use rank_buffer() and place()")
         if self.world > 1:
             dist.gather(self.send, self.recv if self.rank == self.dst else None, dst=self.dst)
-            parts = self.recv
-        else:
-            parts = [self.send]
         if self.rank != self.dst:
             return None
-        for m, part in zip(self.maps, parts):
-            valid = m != PAD
-            self.frame[m[valid]] = part.view(-1, 4)[: len(m)][valid]
+        torch.index_select(self.stacked.view(-1, 4), 0, self.source, out=self.frame)
         return self.frame.view(self.height, self.width, 4)

@@ -24,7 +24,7 @@ EXPORTS = [
     "rt_kernel_time", "rt_synchronize", "rt_version", "rt_debug_eval", "rt_set_option",
     "rt_image_upload", "rt_image_size", "rt_post_blit", "rt_post_color_correction", "rt_post_lut_upload",
     "rt_post_color_grading", "rt_post_bloom", "rt_save_rgb24", "rt_primitives_upload", "rt_trace_primitives",
-    "rt_readback_walk_tree", "rt_trace_rays_device_static",
+    "rt_readback_walk_tree", "rt_trace_rays_device_static", "rt_readback_merge",
 ]
 
 _lib = None
@@ -42,6 +42,13 @@ def load():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError(f"{LIB_PATH} is missing: build it with `make -C raytracing_amd/csrc`")
+        # One HIP runtime per process: the torch wheel carries its own libamdhip64 (soname libamdhip64.so.7, file
+        # name libamdhip64.so).  Loaded first, it also satisfies librtcore's libamdhip64.so.7; loaded second, the
+        # loader takes it for a different library, and the second runtime in a process finds no devices.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         lib.rt_last_error.restype = C.c_char_p
         lib.rt_version.restype = C.c_char_p
@@ -203,6 +210,12 @@ class RtCore:
         img = np.zeros((h, w, 4), np.float32)
         self._check(self.lib.rt_readback(self.ctx, C.c_int(which), _p(img)))
         return img
+
+    def readback_merge(self, which, frame):
+        """Write this context's tiles into `frame` (float32 [height, width, 4], C-contiguous); other pixels are kept."""
+        if frame.dtype != np.float32 or not frame.flags.c_contiguous or frame.shape != (self.params.height, self.params.width, 4):
+            raise ValueError("frame must be a C-contiguous float32 array of shape (height, width, 4)")
+        self._check(self.lib.rt_readback_merge(self.ctx, C.c_int(which), _p(frame)))
 
     def readback_local_device(self, which, device_ptr):
         self._check(self.lib.rt_readback_local_device(self.ctx, C.c_int(which), C.c_void_p(device_ptr)))

@@ -382,6 +382,78 @@ def test_tiles_union_is_bit_identical_to_whole_frame(core):
     H.assert_bits_equal(union, whole, "tile union")
 
 
+def test_two_live_contexts_split_one_frame(core):
+    """Two contexts alive at once (the in-process form of two ranks), each rendering
+    its half of the tiles from a thread of its own; both ways of assembling the frame
+    -- rt_readback_merge on the host, TileGatherer.place on the device -- must give
+    the bits of the undivided render."""
+    import threading
+    import torch
+    from raytracing_amd import dist as rtdist, native
+    sc = scenes.cornell_box(200, 136, sphere_segments=16)
+    seeds = scenes.frame_seeds(3, seed=6)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(sc.params)
+    core.set_dirty()
+    core.render_frames(seeds)
+    whole = core.readback(wire.IMAGE_CONVERGED)
+    whole_shadow = core.readback(wire.IMAGE_SHADOWMAP)
+
+    n = 2
+    parts = [native.RtCore(0) for _ in range(n)]
+    errors = []
+
+    def run(rank):
+        try:
+            c = parts[rank]
+            c.upload(sc)
+            c.bvh_build()
+            p = sc.params.copy()
+            p.tileRank, p.tileCount, p.tileSize = rank, n, 32
+            c.set_params(p)
+            c.set_dirty()
+            c.render_frames(seeds)
+        except Exception as e:          # noqa: BLE001 -- reported by the main thread
+            errors.append((rank, e))
+
+    try:
+        threads = [threading.Thread(target=run, args=(r,)) for r in range(n)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        merged = np.full_like(whole, np.float32(-1))
+        merged_shadow = np.full_like(whole, np.float32(-1))
+        for c in parts:
+            c.readback_merge(wire.IMAGE_CONVERGED, merged)
+            c.readback_merge(wire.IMAGE_SHADOWMAP, merged_shadow)
+        H.assert_bits_equal(merged, whole, "rt_readback_merge of two contexts")
+        H.assert_bits_equal(merged_shadow, whole_shadow, "rt_readback_merge of two contexts (shadow map)")
+        # one context alone leaves the other's pixels untouched
+        alone = np.full_like(whole, np.float32(-1))
+        parts[0].readback_merge(wire.IMAGE_CONVERGED, alone)
+        pm = parts[0].local_pixel_map()
+        own = np.zeros(whole.shape[0] * whole.shape[1], bool)
+        own[pm[pm != 0xFFFFFFFF]] = True
+        own = own.reshape(whole.shape[:2])
+        assert (alone[~own] == -1).all() and np.array_equal(alone[own].view(np.uint32), whole[own].view(np.uint32))
+        with pytest.raises(ValueError):
+            parts[0].readback_merge(wire.IMAGE_CONVERGED, np.zeros((4, 4, 4), np.float32))
+        # device-side placement
+        g = rtdist.TileGatherer(sc.params.width, sc.params.height, 32, torch.device("cuda:0"), contexts=n)
+        for r, c in enumerate(parts):
+            buf = g.rank_buffer(r)
+            assert buf.numel() == c.local_pixel_count * 4
+            c.readback_local_device(wire.IMAGE_CONVERGED, buf.data_ptr())
+        torch.cuda.synchronize()
+        H.assert_bits_equal(g.place().cpu().numpy(), whole, "TileGatherer.place of two contexts")
+    finally:
+        for c in parts:
+            c.close()
+
+
 def test_resume_from_uploaded_accumulator(core):
     sc = scenes.cornell_box(64, 64, sphere_segments=16)
     seeds = scenes.frame_seeds(4, seed=8)

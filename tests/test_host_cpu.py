@@ -82,6 +82,77 @@ int main(void) {
     assert out[15] == C.sizeof(wire.RtStats) and out[16] == wire.TRIANGLE.fields["materialIndex"][1]
 
 
+def test_batch_frames_rule_keeps_ray_indices_in_32_bits():
+    """Frames in flight: 128 M paths at most and never more than 64 frames; an explicit option is held to the
+    same path budget, so 16 shadow rays per path still index in 32 bits (the rule is a host function)."""
+    lib = native.load()
+    f = lib.rt_debug_batch_frames
+    f.restype = C.c_uint32
+    f.argtypes = [C.c_uint32] * 3
+    hd, uhd = 1920 * 1080, 3840 * 2160
+    assert f(hd, 0, 1000) == 64 and f(uhd, 0, 1000) == 16 and f(hd, 0, 5) == 5 and f(hd, 0, 0) == 1
+    assert f(hd, 8, 1000) == 8 and f(hd, 1000, 1000) == 64 and f(uhd, 64, 1000) == 16      # the option cannot lift the path budget
+    assert f(0, 0, 3) == 3 and f(1 << 27, 0, 9) == 1 and f((1 << 28) - 1, 64, 9) == 1
+    for slots in (1, 4096, hd, uhd, 7680 * 4320, (1 << 28) - 1):
+        for option in (0, 1, 7, 64, 4000):
+            got = f(slots, option, 1 << 20)
+            assert 1 <= got <= 64 and (got == 1 or slots * got * 16 < 1 << 32), (slots, option, got)
+
+
+def _c_prototypes():
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rtcore.h")).read(), flags=re.S)
+    protos = {}
+    for m in re.finditer(r"^(int|uint32_t|const char \*)\s*(rt_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.M | re.S):
+        args = [" ".join(a.split()) for a in m.group(3).split(",")]
+        protos[m.group(2)] = (m.group(1).strip(), [] if args == ["void"] else args)
+    return protos
+
+
+def _kind_c(arg):
+    if "*" in arg:
+        return "pointer"
+    t = arg.rsplit(" ", 1)[0].replace("const ", "")
+    return {"int": "i32", "int32_t": "i32", "uint32_t": "u32", "float": "f32"}[t]
+
+
+def _kind_cs(arg):
+    words = arg.split()
+    if words[0] in ("ref", "out") or words[0].endswith("[]") or words[0] in ("IntPtr", "string"):
+        return "pointer"
+    return {"int": "i32", "uint": "u32", "float": "f32"}[words[0]]
+
+
+def test_csharp_binding_declares_every_export_with_matching_arguments():
+    """The Unity-side binding cannot be compiled here, so its declarations are checked as text:
+    every prototype of the header has exactly one [DllImport], with the same number of arguments and
+    the same scalar-or-pointer kind in every position, and no argument is an untyped System.Array."""
+    text = open(os.path.join(ROOT, "csharp", "RtCoreNative.cs")).read()
+    code = re.sub(r"//[^\n]*", "", text)
+    found = re.findall(r"\[DllImport\(Lib[^\]]*\)\]\s*public static extern (\w+) (rt_\w+)\(([^)]*)\)\s*;", code)
+    names = [n for _, n, _ in found]
+    assert len(names) == len(set(names))
+    protos = _c_prototypes()
+    assert set(names) == set(protos), (set(protos) - set(names), set(names) - set(protos))
+    assert set(protos) == set(native.EXPORTS)
+    for ret, name, args in found:
+        c_ret, c_args = protos[name]
+        cs_args = [" ".join(a.split()) for a in args.split(",")] if args.strip() else []
+        assert len(cs_args) == len(c_args), name
+        assert ret == {"int": "int", "uint32_t": "uint", "const char *": "IntPtr"}[c_ret], name
+        for a, b in zip(cs_args, c_args):
+            assert not a.startswith("Array "), (name, a)
+            assert _kind_cs(a) == _kind_c(b), (name, a, b)
+    # the counters struct: as many 8-byte fields as the C struct holds, doubles in the same places
+    body = re.search(r"public struct RtStats[^{]*\{(.*?)\n    \}", code, flags=re.S).group(1)
+    fields = []
+    for kind, lst in re.findall(r"public (ulong|double) ([^;]+);", body):
+        fields += [kind] * len(lst.split(","))
+    want = ["double" if isinstance(t, type) and t is C.c_double else "ulong" for _, t in wire.RtStats._fields_]
+    assert fields == want
+    for const in ("RT_OPT_CASTER_BOX = 10", "RT_TRACE_STATIC_MAX_RAYS = 1u << 24", "RT_IMAGE_USER = 4"):
+        assert const in code
+
+
 # ------------------------------------------------------------------ scene / host logic
 def test_material_data_follows_the_reference_override_order():
     m = scenes.material_data((0.5, 0.5, 0.5, 0.25), 0.0, 0.0)
@@ -92,6 +163,35 @@ def test_material_data_follows_the_reference_override_order():
     e = scenes.material_data((1, 1, 1, 0.5), mode=3, emission=(2, 3, 4))
     assert e["materialType"] == 2 and tuple(e["emissionColor"]) == (2, 3, 4)   # emission wins over transparent
     assert scenes.material_data()["ior"] == 1.0
+
+
+def test_material_presets_follow_the_reference_table():
+    """CustomMaterialInfo.cs:21-102 on stand-in renderers Sphere_0..Sphere_5 (ratio k/5), without a device."""
+    from types import SimpleNamespace
+    rs = [SimpleNamespace(name=f"Sphere_{k}", sharedMaterial=host.Material(color=(0.8, 0.6, 0.4, 1.0))) for k in range(6)]
+    info = host.CustomMaterialInfo(SimpleNamespace(core=None), rs)
+    table = lambda: np.array([r.sharedMaterial.MaterialData() for r in rs], wire.MATERIAL)
+    ratio = np.arange(6, dtype=np.float32) / 5
+    info.OnMaterialChanged(0)                                  # dielectric, smoothness sweep
+    m = table()
+    assert (m["metallic"] == np.float32(0.01)).all() and (m["materialType"] == 0).all() and (m["transparent"] == -1).all()
+    np.testing.assert_array_equal(m["smoothness"], np.maximum(ratio, np.float32(0.01)))
+    info.OnMaterialChanged(1)                                  # metal, smoothness sweep
+    m = table()
+    assert (m["metallic"] == 1).all() and (m["ior"] == 1).all()
+    info.OnMaterialChanged(3)                                  # glass, ior sweep 1.0 .. 1.5
+    m = table()
+    assert (m["materialType"] == 1).all() and (m["transparent"] == np.float32(0.1)).all() and (m["smoothness"] == 1).all()
+    np.testing.assert_allclose(m["ior"], 1 + ratio * 0.5, rtol=1e-6)
+    info.OnMaterialChanged(4)                                  # clear coat: opaque again (mode 0), type 3
+    m = table()
+    assert (m["materialType"] == 3).all() and (m["transparent"] == -1).all() and (m["metallic"] == 1).all()
+    info.OnMaterialChanged(5)                                  # transparency sweep
+    m = table()
+    np.testing.assert_array_equal(m["transparent"], ratio)
+    assert (m["ior"] == np.float32(1.1)).all()
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "unity_chapter6_5_scene.npz"))["materials_preset"]
+    assert gold.shape[0] == 6 and gold.dtype == wire.MATERIAL
 
 
 def test_cornell_scene_geometry():
@@ -149,6 +249,38 @@ def test_tile_map_partitions_the_frame():
         assert (seen == 1).all()
     m = rtdist.tile_pixel_map(64, 64, 64, 0, 1)
     assert m[:8].tolist() == list(range(8)) and m[8] == 64 and m[64] == 8          # 8x8 blocks, row-major inside
+
+
+def test_tile_gatherer_places_by_a_precomputed_permutation():
+    import torch
+    w, h, ts = 200, 136, 32
+    for n in (1, 2, 5):
+        g = rtdist.TileGatherer(w, h, ts, torch.device("cpu"), contexts=n)
+        assert g.source.dtype == torch.int64 and len(g.source) == w * h and len(set(g.source.tolist())) == w * h
+        for twice in range(2):                                                     # buffers are reused from image to image
+            for r in range(n):
+                m = rtdist.tile_pixel_map(w, h, ts, r, n)
+                local = np.full((len(m), 4), -7.0, np.float32)                     # padding slots carry a value that must not land
+                ok = m != rtdist.PAD
+                local[ok, 0], local[ok, 1], local[ok, 2] = m[ok], r, twice
+                g.rank_buffer(r).copy_(torch.from_numpy(local.reshape(-1)))
+            f = g.place().numpy()
+            assert np.array_equal(f[..., 0].reshape(-1), np.arange(w * h, dtype=np.float32))
+            ty, tx = np.mgrid[0:h, 0:w]
+            owner = ((ty // ts) * ((w + ts - 1) // ts) + tx // ts) % n
+            assert np.array_equal(f[..., 1], owner.astype(np.float32)) and (f[..., 2] == twice).all()
+        with pytest.raises(RuntimeError):
+            g.gather()
+    single = rtdist.TileGatherer(64, 64, 64, torch.device("cpu"))                  # no process group: world of one
+    single.local_buffer().copy_(torch.arange(64 * 64 * 4, dtype=torch.float32))
+    m = rtdist.tile_pixel_map(64, 64, 64, 0, 1)
+    assert np.array_equal(single.gather().numpy().reshape(-1, 4)[m][:, 0], np.arange(64 * 64, dtype=np.float32) * 4)
+
+
+def test_scene_broadcast_refuses_primitive_lists():
+    import torch
+    with pytest.raises(ValueError):                                                # raised before any collective is entered
+        rtdist.broadcast_scene(scenes.primitive_room(32, 32), torch.device("cpu"))
 
 
 # ------------------------------------------------------------------ world_size 2 on gloo
