@@ -77,6 +77,14 @@ static int use_device(RtContext *ctx)
         if (rc__) return rc__;                          \
     }
 
+// Entry points that change what a ShadowMap pass started by rt_dispatch works on (or reuse its buffers) drop that pass first.
+#define RT_ENTER_CHANGING(ctx)                                   \
+    RT_ENTER(ctx);                                               \
+    do {                                                         \
+        const int eagerRc_ = rt_eager_cancel(ctx);               \
+        if (eagerRc_) return eagerRc_;                           \
+    } while (0)
+
 template <typename T>
 static int upload(RtContext *ctx, T **dst, const T *src, size_t count)
 {
@@ -172,7 +180,7 @@ const char *rt_last_error(RtContext *ctx) { return ctx ? ctx->err.c_str() : "nul
 int rt_scene_upload(RtContext *ctx, const RtMeshVertex *vertices, uint32_t n_vertices, const uint32_t *indices,
                     uint32_t n_indices, const uint32_t *material_index, const int32_t *shadow_index_xy, uint32_t n_triangles)
 {
-    RT_ENTER(ctx);
+    RT_ENTER_CHANGING(ctx);
     if (n_indices != 3ull * n_triangles) return rt_fail(ctx, RT_E_INVALID, "n_indices (%u) != 3 * n_triangles (%u)", n_indices, n_triangles);
     if (n_triangles && (!vertices || !indices || !material_index || !shadow_index_xy))
         return rt_fail(ctx, RT_E_INVALID, "null scene array");
@@ -228,7 +236,7 @@ int rt_scene_upload(RtContext *ctx, const RtMeshVertex *vertices, uint32_t n_ver
 
 int rt_materials_upload(RtContext *ctx, const RtMaterialData *materials, uint32_t n)
 {
-    RT_ENTER(ctx);
+    RT_ENTER_CHANGING(ctx);
     if (n && !materials) return rt_fail(ctx, RT_E_INVALID, "null materials");
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int rc;
@@ -241,7 +249,7 @@ int rt_materials_upload(RtContext *ctx, const RtMaterialData *materials, uint32_
 int rt_lights_upload(RtContext *ctx, const RtSphereLight *sphere, uint32_t n_sphere, const RtAreaLight *area, uint32_t n_area,
                      const RtDiscLight *disc, uint32_t n_disc)
 {
-    RT_ENTER(ctx);
+    RT_ENTER_CHANGING(ctx);
     if ((n_sphere && !sphere) || (n_area && !area) || (n_disc && !disc)) return rt_fail(ctx, RT_E_INVALID, "null light array");
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int rc;
@@ -256,7 +264,7 @@ int rt_lights_upload(RtContext *ctx, const RtSphereLight *sphere, uint32_t n_sph
 
 int rt_skybox_upload(RtContext *ctx, const float *faces_rgba, uint32_t size)
 {
-    RT_ENTER(ctx);
+    RT_ENTER_CHANGING(ctx);
     if (size && !faces_rgba) return rt_fail(ctx, RT_E_INVALID, "null skybox");
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int rc;
@@ -267,7 +275,7 @@ int rt_skybox_upload(RtContext *ctx, const float *faces_rgba, uint32_t size)
 
 int rt_bvh_build(RtContext *ctx)
 {
-    RT_ENTER(ctx);
+    RT_ENTER_CHANGING(ctx);
     if (ctx->N && !ctx->dVerts) return rt_fail(ctx, RT_E_STATE, "rt_bvh_build before rt_scene_upload");
     const int rc = rt_build_impl(ctx);
     rt_timer_resolve(ctx);
@@ -312,7 +320,7 @@ int rt_readback_sort_stages(RtContext *ctx, uint32_t *morton_unsorted, uint32_t 
 
 int rt_set_params(RtContext *ctx, const RtParams *p)
 {
-    RT_ENTER(ctx);
+    RT_ENTER_CHANGING(ctx);
     if (!p) return rt_fail(ctx, RT_E_INVALID, "null params");
     if (p->width <= 0 || p->height <= 0 || p->width > 32768 || p->height > 32768)
         return rt_fail(ctx, RT_E_INVALID, "bad image size %d x %d", p->width, p->height);
@@ -508,7 +516,7 @@ int rt_local_pixel_map(RtContext *ctx, uint32_t *dst)
 
 int rt_trace_rays_device(RtContext *ctx, const void *device_origins4, const void *device_dirs4, uint32_t n, void *device_hits4)
 {
-    RT_ENTER(ctx);
+    RT_ENTER_CHANGING(ctx);
     if (!ctx->built) return rt_fail(ctx, RT_E_STATE, "rt_bvh_build has not been called");
     if (n && (!device_origins4 || !device_dirs4 || !device_hits4)) return rt_fail(ctx, RT_E_INVALID, "null ray buffers");
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -530,7 +538,7 @@ int rt_trace_rays_device(RtContext *ctx, const void *device_origins4, const void
 
 int rt_trace_rays_device_static(RtContext *ctx, const void *device_origins4, const void *device_dirs4, uint32_t n, void *device_hits4)
 {
-    RT_ENTER(ctx);
+    RT_ENTER_CHANGING(ctx);
     if (!ctx->built) return rt_fail(ctx, RT_E_STATE, "rt_bvh_build has not been called");
     if (n > RT_TRACE_STATIC_MAX_RAYS)
         return rt_fail(ctx, RT_E_INVALID, "rt_trace_rays_device_static: %u rays exceed the maximum of %u per call", n, RT_TRACE_STATIC_MAX_RAYS);
@@ -541,7 +549,7 @@ int rt_trace_rays_device_static(RtContext *ctx, const void *device_origins4, con
 int rt_trace_rays(RtContext *ctx, const float *origins, const float *directions, uint32_t n, float *out_t, uint32_t *out_triangle,
                   float *out_u, float *out_v)
 {
-    RT_ENTER(ctx);
+    RT_ENTER_CHANGING(ctx);
     if (!ctx->built) return rt_fail(ctx, RT_E_STATE, "rt_bvh_build has not been called");
     if (n == 0) return RT_OK;
     if (!origins || !directions) return rt_fail(ctx, RT_E_INVALID, "null rays");
@@ -574,7 +582,7 @@ int rt_trace_rays(RtContext *ctx, const float *origins, const float *directions,
 
 int rt_debug_eval(RtContext *ctx, int which, const float *x, const float *y, uint32_t n, float *out)
 {
-    RT_ENTER(ctx);
+    RT_ENTER_CHANGING(ctx);
     if (!x || !y || !out || n == 0) return rt_fail(ctx, RT_E_INVALID, "bad rt_debug_eval arguments");
     const uint32_t nin = which == 7 ? 2u : (which == 8 ? 15u : n);
     float *dx = nullptr, *dy = nullptr, *dout = nullptr;
@@ -595,8 +603,9 @@ int rt_debug_eval(RtContext *ctx, int which, const float *x, const float *y, uin
 
 int rt_set_option(RtContext *ctx, int option, int value)
 {
-    if (!ctx) return RT_E_INVALID;
+    RT_ENTER_CHANGING(ctx);
     switch (option) {
+    case RT_OPT_EAGER_SHADOWMAP: ctx->optEagerShadowMap = value != 0; return RT_OK;
     case RT_OPT_PACKET_SHADOW: ctx->optPacketShadow = value != 0; return RT_OK;
     case RT_OPT_PACKET_PRIMARY: ctx->optPacketPrimary = value != 0; return RT_OK;
     case RT_OPT_PACKET_TRACE: ctx->optPacketTrace = value != 0; return RT_OK;
@@ -623,14 +632,14 @@ int rt_set_option(RtContext *ctx, int option, int value)
 
 int rt_enable_counters(RtContext *ctx, int enable)
 {
-    if (!ctx) return RT_E_INVALID;
+    RT_ENTER_CHANGING(ctx);
     ctx->countersOn = enable != 0;
     return RT_OK;
 }
 
 int rt_enable_kernel_timing(RtContext *ctx, int enable)
 {
-    if (!ctx) return RT_E_INVALID;
+    RT_ENTER_CHANGING(ctx);
     rt_timer_resolve(ctx);
     ctx->timingOn = enable != 0;
     return RT_OK;
@@ -698,7 +707,7 @@ int rt_kernel_time(RtContext *ctx, const char *kernel_name, double *out_total_ms
 
 int rt_synchronize(RtContext *ctx)
 {
-    RT_ENTER(ctx);
+    RT_ENTER_CHANGING(ctx);
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     rt_timer_resolve(ctx);
     return check_error_flag(ctx);

@@ -1018,14 +1018,21 @@ static int overlap_fork(RtContext *ctx, const RtSceneView &sceneView, uint32_t t
     return RT_OK;
 }
 
-// After the last bounce: back to the main stream, which helps with the shadow rays from the units the bounces had.
-static int overlap_join(RtContext *ctx, const RtSceneView &sceneView, uint32_t total)
+// After the last bounce: back to the main stream, which waits for the chain stream's work.
+static int overlap_chain_done(RtContext *ctx)
 {
+    if (!ctx->streamMain) return RT_OK;
     hipStream_t chain = ctx->stream;
     ctx->stream = ctx->streamMain;
     ctx->streamMain = nullptr;
     RT_HIP(ctx, hipEventRecord(ctx->evFork, chain));
     RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evFork, 0));
+    return RT_OK;
+}
+
+// The main stream helps with the shadow rays from the units the bounces had, then folds the results.
+static int overlap_finish(RtContext *ctx, const RtSceneView &sceneView, uint32_t total)
+{
     RtSceneView sv = sceneView;
     sv.stats = ctx->dStats + 32;
     ShadowSrcOverlapped sh;
@@ -1037,6 +1044,12 @@ static int overlap_join(RtContext *ctx, const RtSceneView &sceneView, uint32_t t
     RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evJoin, 0));
     launch_sm_resolve(ctx, total);
     return RT_OK;
+}
+
+static int overlap_join(RtContext *ctx, const RtSceneView &sceneView, uint32_t total)
+{
+    const int rc = overlap_chain_done(ctx);
+    return rc ? rc : overlap_finish(ctx, sceneView, total);
 }
 
 // CSMain for `frames` frames of the current view (seeds already in dSeeds).
@@ -1126,18 +1139,59 @@ static int upload_seeds(RtContext *ctx, const float *seeds, uint32_t n)
     return RT_OK;
 }
 
+static int overlap_choice(RtContext *ctx, bool shared)
+{
+    // Per-launch counters and event timers describe launches of one stream, one after the other: both keep the plain order.
+    if (shared && ctx->optOverlapShadow && !ctx->optTwoStreams && !ctx->countersOn && !ctx->timingOn && !ctx->optPacketShadow &&
+        !(ctx->params.flags & RT_FLAG_BRUTE_FORCE) && ctx->tile.nSlots != 0 && ctx->optOverlapAfter + 1 < RT_MAX_BOUNCE &&
+        overlap_streams_ready(ctx))
+        return (int)ctx->optOverlapAfter;
+    return -1;
+}
+
+// A ShadowMap pass that rt_dispatch started and nobody asked for yet is dropped: the main stream waits for
+// its launch (the buffers it works on are about to be reused) and the next rt_dispatch_shadowmap starts over.
+int rt_eager_cancel(RtContext *ctx)
+{
+    const int state = ctx->eagerShadow;
+    ctx->eagerShadow = RT_EAGER_NONE;
+    if (state == RT_EAGER_FORKED) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evJoin, 0));
+    return RT_OK;
+}
+
+// CSMain of one frame.  When the parameters say that the ShadowMap kernel follows (RT_FLAG_MATTE_MASK:
+// RayTracing.cs:134-135 dispatches it right after CSMain, same uniforms) and it traces the same primary rays,
+// its pass is prepared from CSMain's primary hits here and its 16 rays per pixel are walked while the later
+// bounces run; rt_dispatch_shadowmap then only drains and folds.  Work counters keep the two kernels apart.
 int rt_dispatch_impl(RtContext *ctx)
 {
-    int rc = upload_seeds(ctx, &ctx->params.seed, 1);
+    int rc = rt_eager_cancel(ctx);
     if (rc) return rc;
-    return dispatch_frames(ctx, 1, false);
+    if ((rc = upload_seeds(ctx, &ctx->params.seed, 1))) return rc;
+    const bool eager = ctx->optEagerShadowMap && (ctx->params.flags & RT_FLAG_MATTE_MASK) && shadow_shares_primary(ctx->params) &&
+                       ctx->built && !ctx->countersOn && ctx->tile.nSlots != 0;
+    if (!eager) return dispatch_frames(ctx, 1, false);
+    const int overlapAfter = overlap_choice(ctx, true);
+    rc = dispatch_frames(ctx, 1, true, overlapAfter);
+    const int rc2 = overlap_chain_done(ctx);
+    if (rc || rc2) return rc ? rc : rc2;
+    ctx->eagerShadow = overlapAfter >= 0 ? RT_EAGER_FORKED : RT_EAGER_SETUP;
+    return RT_OK;
 }
 
 int rt_shadowmap_impl(RtContext *ctx)
 {
+    const int state = ctx->eagerShadow;
+    ctx->eagerShadow = RT_EAGER_NONE;
+    ctx->lastFrame = 0;
+    if (state == RT_EAGER_FORKED) return overlap_finish(ctx, rt_scene_view(ctx), ctx->tile.nSlots);
+    if (state == RT_EAGER_SETUP) {
+        launch_shadow_rays(ctx, rt_scene_view(ctx), ctx->tile.nSlots);
+        RT_HIP(ctx, hipGetLastError());
+        return RT_OK;
+    }
     int rc = upload_seeds(ctx, &ctx->params.seed, 1);
     if (rc) return rc;
-    ctx->lastFrame = 0;
     return shadowmap_frames(ctx, 1);
 }
 
@@ -1194,12 +1248,7 @@ struct RtLaneScope {
 
 static int render_lane(RtContext *ctx, uint32_t frames, bool matte, bool shared)
 {
-    // Per-launch counters and event timers describe launches of one stream, one after the other: both keep the plain order.
-    int overlapAfter = -1;
-    if (shared && ctx->optOverlapShadow && !ctx->optTwoStreams && !ctx->countersOn && !ctx->timingOn && !ctx->optPacketShadow &&
-        !(ctx->params.flags & RT_FLAG_BRUTE_FORCE) && ctx->tile.nSlots != 0 && ctx->optOverlapAfter + 1 < RT_MAX_BOUNCE &&
-        overlap_streams_ready(ctx))
-        overlapAfter = (int)ctx->optOverlapAfter;
+    const int overlapAfter = overlap_choice(ctx, shared);
     int rc = dispatch_frames(ctx, frames, shared, overlapAfter);
     if (rc || !matte) {
         if (ctx->streamMain) {                   // left the bounce loop on the chain stream
@@ -1227,6 +1276,7 @@ int rt_render_frames_impl(RtContext *ctx, const float *seeds, uint32_t nFrames)
         rc = alloc_batch(ctx, batch);
     }
     if (rc) return rc;
+    if ((rc = rt_eager_cancel(ctx))) return rc;
     for (uint32_t base = 0; base < nFrames; base += batch) {
         const uint32_t f = nFrames - base < batch ? nFrames - base : batch;
         if ((rc = upload_seeds(ctx, seeds + base, f))) return rc;

@@ -212,6 +212,8 @@ struct RtContext {
     bool optCasterBox = true;             // shadow rays that cannot meet a shadow caster are not walked
     bool optFirstHitShadow = true;        // shadow rays that cannot meet a non-casting triangle stop at their first hit
     bool optOverlapShadow = true;         // walk the shadow rays while the later bounces run (render.hip, overlap_fork)
+    bool optEagerShadowMap = true;        // rt_dispatch starts the ShadowMap pass of its frame (render.hip, rt_dispatch_impl)
+    int eagerShadow = 0;                  // RT_EAGER_*: what rt_dispatch left for rt_dispatch_shadowmap
     uint32_t optOverlapAfter = 0;         // ... from the extend launch of this bounce on
     uint32_t optOverlapCUs = 64;          // compute units the bounce launches keep meanwhile
     uint32_t optBatchFrames = 0;          // 0 = by path count (rt_batch_frames)
@@ -271,6 +273,8 @@ void rt_free_build(RtContext *ctx);
 // render.hip
 RtSceneView rt_scene_view(RtContext *ctx);
 int rt_alloc_render(RtContext *ctx);
+enum { RT_EAGER_NONE = 0, RT_EAGER_SETUP = 1, RT_EAGER_FORKED = 2 };   // nothing / pass prepared / its rays already being walked
+int rt_eager_cancel(RtContext *ctx);
 uint32_t rt_batch_frames_rule(uint32_t nSlots, uint32_t option, uint32_t wanted);
 void rt_free_render(RtContext *ctx);
 int rt_dispatch_impl(RtContext *ctx);

@@ -454,6 +454,52 @@ def test_two_live_contexts_split_one_frame(core):
             c.close()
 
 
+def test_shadowmap_pass_started_by_dispatch_gives_the_same_bits(core):
+    """rt_dispatch may start the ShadowMap pass of its frame (RT_OPT_EAGER_SHADOWMAP); with the option on or off, and
+    when the prepared pass is dropped by a call in between, the three images keep their bits."""
+    sc = scenes.car_standin(192, 128, detail=0.08)               # matte-mask ground under a shadow caster, depth of field
+    assert sc.params.flags & wire.FLAG_MATTE_MASK
+    seeds = scenes.frame_seeds(3, seed=12)
+    core.upload(sc)
+    core.bvh_build()
+
+    def run(eager, disturb=None):
+        core.set_option(wire.OPT_EAGER_SHADOWMAP, eager)
+        p = sc.params.copy()
+        core.set_params(p)
+        core.set_dirty()
+        for k, seed in enumerate(seeds):
+            p.seed = float(seed)
+            core.set_params(p)
+            core.dispatch()
+            if disturb == "dispatch_again":
+                core.dispatch()
+            elif disturb == "option":
+                core.set_option(wire.OPT_CASTER_BOX, 1)
+            elif disturb == "params":
+                core.set_params(p)
+            core.dispatch_shadowmap()
+            core.accumulate(k, True)
+        return [core.readback(w) for w in (wire.IMAGE_RT, wire.IMAGE_SHADOWMAP, wire.IMAGE_CONVERGED)]
+
+    try:
+        want = run(0)
+        assert want[1].min() < want[1].max()                     # the shadow map is not flat
+        for disturb in (None, "dispatch_again", "option", "params"):
+            got = run(1, disturb)
+            for name, a, b in zip(("rt", "shadow map", "converged"), got, want):
+                H.assert_bits_equal(a, b, f"{name}, eager ShadowMap pass, {disturb}")
+        # a ShadowMap pass on its own (no rt_dispatch before it) still traces its own primary rays
+        core.set_option(wire.OPT_EAGER_SHADOWMAP, 1)
+        p = sc.params.copy()
+        p.seed = float(seeds[-1])
+        core.set_params(p)
+        core.dispatch_shadowmap()
+        H.assert_bits_equal(core.readback(wire.IMAGE_SHADOWMAP), want[1], "stand-alone ShadowMap pass")
+    finally:
+        core.set_option(wire.OPT_EAGER_SHADOWMAP, 1)
+
+
 def test_resume_from_uploaded_accumulator(core):
     sc = scenes.cornell_box(64, 64, sphere_segments=16)
     seeds = scenes.frame_seeds(4, seed=8)

@@ -149,7 +149,7 @@ def test_csharp_binding_declares_every_export_with_matching_arguments():
         fields += [kind] * len(lst.split(","))
     want = ["double" if isinstance(t, type) and t is C.c_double else "ulong" for _, t in wire.RtStats._fields_]
     assert fields == want
-    for const in ("RT_OPT_CASTER_BOX = 10", "RT_TRACE_STATIC_MAX_RAYS = 1u << 24", "RT_IMAGE_USER = 4"):
+    for const in ("RT_OPT_EAGER_SHADOWMAP = 11", "RT_TRACE_STATIC_MAX_RAYS = 1u << 24", "RT_IMAGE_USER = 4"):
         assert const in code
 
 
