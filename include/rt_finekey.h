@@ -37,7 +37,7 @@ typedef struct RtKeyPlan {
     float tierLimit[3];      /* a box whose largest extent exceeds tierLimit[k] is of size class <= k */
 } RtKeyPlan;
 
-static inline RtKeyPlan rt_key_plan(const float mn[3], const float mx[3])
+RT_HD RtKeyPlan rt_key_plan(const float mn[3], const float mx[3])
 {
     RtKeyPlan p;
     float cell[3];

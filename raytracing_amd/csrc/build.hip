@@ -402,19 +402,39 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_compact_undone(uint32_t nAl
     }
 }
 
-// ------------------------------------------------------------------ tree rotations (traversal tree only)
-// One bottom-up pass of include/rt_rotate.h, level by level like k_fit: node i is handled in launch `iter`
-// when its internal children were handled in an earlier launch.  A swap rewrites the links of i and of
-// the child that changes and that child's box; nobody else reads those before a later launch (the child
-// is finished, i's parent waits for i).  Parent pointers are not kept up (nothing reads them afterwards).
-__device__ __forceinline__ void load_box(uint32_t child, const uint32_t *__restrict__ sortedIdx, const float4 *__restrict__ triAABB,
-                                         const float4 *bvhData, float out[6])
+// ------------------------------------------------------------------ traversal tree: fit and tree rotations in one sweep
+// The tree the rays walk gets its boxes (pass 1, the union k_fit computes) and then RT_ROTATION_PASSES bottom-up
+// passes of include/rt_rotate.h (passes 2, 3, ...).  Run pass after pass and level after level that is
+// (1 + passes) x height launches.  The passes overlap instead, as a wavefront: in every launch of the sweep a
+// node takes its NEXT pass p if, in EARLIER launches,
+//   (a) its internal children finished pass p (their subtrees are as pass p leaves them), and
+//   (b) for p >= 3, its parent finished pass p - 1 (the only other node whose rotation rewrites this node's
+//       links and box has made that pass's change to them).
+// A rotation at node i reads the links of i and of its children and the boxes of its children and
+// grandchildren, and rewrites the links of i, the links and box of the child that changes and the parent words
+// of what moved.  With (a) and (b) nothing it reads can be rewritten in the same launch (i's parent waits for i
+// by (a), i's children wait for i by (b), a grandparent's rotation moves i as a whole, and a node's own
+// rotation never changes its own box), every read of another workgroup's result is ordered by a kernel
+// boundary, and every decision sees what it sees when the passes run one after the other: the outcome is the
+// one of the serial, post-order passes of the checker, in height + 2 x passes launches.
+// prog[i] = passes finished << 8 | launch that finished the last one (launches count from 1).
+#define SWEEP_PASSES(w) ((w) >> 8)
+#define SWEEP_LAUNCH(w) ((w) & 255u)
+#define SWEEP_MAX_LAUNCH 255u
+__device__ __forceinline__ bool sweep_finished_before(uint32_t w, uint32_t pass, uint32_t iter)
+{
+    return SWEEP_PASSES(w) > pass || (SWEEP_PASSES(w) == pass && SWEEP_LAUNCH(w) < iter);
+}
+
+// leafBox: the triangles' boxes in the order of this tree's leaves (k_gather_leaf_boxes), so that the leaves under a
+// node, neighbours in that order, are neighbours in memory in every pass instead of scattered over the input order
+__device__ __forceinline__ void load_box(uint32_t child, const float4 *__restrict__ leafBox, const float4 *bvhData, float out[6])
 {
     float4 mn, mx;
     if (child & RT_LEAF_BIT) {
-        const uint32_t t = sortedIdx[child & ~RT_LEAF_BIT];
-        mn = triAABB[t * 2];
-        mx = triAABB[t * 2 + 1];
+        const uint32_t t = child & ~RT_LEAF_BIT;
+        mn = leafBox[t * 2];
+        mx = leafBox[t * 2 + 1];
     } else {
         mn = bvhData[child * 2];
         mx = bvhData[child * 2 + 1];
@@ -422,82 +442,183 @@ __device__ __forceinline__ void load_box(uint32_t child, const uint32_t *__restr
     out[0] = mn.x; out[1] = mn.y; out[2] = mn.z; out[3] = mx.x; out[4] = mx.y; out[5] = mx.z;
 }
 
-__global__ __launch_bounds__(256) void k_rotate(uint32_t nAll, const uint32_t *__restrict__ list, const uint32_t *__restrict__ listCount, uint32_t iter, uint32_t *left, uint32_t *right,
-                                                 const uint32_t *__restrict__ sortedIdx, const float4 *__restrict__ triAABB,
-                                                 float4 *bvhData, uint32_t *done)
+__global__ __launch_bounds__(256) void k_gather_leaf_boxes(uint32_t N, const uint32_t *__restrict__ sortedIdx, const float4 *__restrict__ triAABB,
+                                                            float4 *__restrict__ leafBox)
 {
-    const uint32_t n = list ? *listCount : nAll;
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-    const uint32_t i = list ? list[k] : k;
-    if (done[i] != FIT_UNDONE) continue;
-    const uint32_t l = left[i], r = right[i];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t t = sortedIdx[i];
+    leafBox[i * 2] = triAABB[t * 2];
+    leafBox[i * 2 + 1] = triAABB[t * 2 + 1];
+}
+
+__device__ __forceinline__ void store_box(float4 *bvhData, uint32_t node, const float m[6])
+{
+    bvhData[node * 2 + 0] = make_float4(m[0], m[1], m[2], 0.0f);
+    bvhData[node * 2 + 1] = make_float4(m[3], m[4], m[5], 0.0f);
+}
+
+__device__ __forceinline__ void set_parent(uint32_t *parent, uint32_t child, uint32_t to)
+{
+    if (!(child & RT_LEAF_BIT)) parent[child] = to;
+}
+
+__device__ __forceinline__ void rotate_node(uint32_t i, uint32_t l, uint32_t r, uint32_t *left, uint32_t *right, uint32_t *parent,
+                                            const float4 *__restrict__ leafBox, float4 *bvhData)
+{
     const bool lInt = !(l & RT_LEAF_BIT), rInt = !(r & RT_LEAF_BIT);
-    if (lInt && done[l] >= iter) continue;
-    if (rInt && done[r] >= iter) continue;
     float L[6], R[6], La[6] = {0, 0, 0, 0, 0, 0}, Lb[6] = {0, 0, 0, 0, 0, 0}, Ra[6] = {0, 0, 0, 0, 0, 0}, Rb[6] = {0, 0, 0, 0, 0, 0};
     uint32_t la = 0, lb = 0, ra = 0, rb = 0;
-    load_box(l, sortedIdx, triAABB, bvhData, L);
-    load_box(r, sortedIdx, triAABB, bvhData, R);
+    load_box(l, leafBox, bvhData, L);
+    load_box(r, leafBox, bvhData, R);
     if (lInt) {
         la = left[l]; lb = right[l];
-        load_box(la, sortedIdx, triAABB, bvhData, La);
-        load_box(lb, sortedIdx, triAABB, bvhData, Lb);
+        load_box(la, leafBox, bvhData, La);
+        load_box(lb, leafBox, bvhData, Lb);
     }
     if (rInt) {
         ra = left[r]; rb = right[r];
-        load_box(ra, sortedIdx, triAABB, bvhData, Ra);
-        load_box(rb, sortedIdx, triAABB, bvhData, Rb);
+        load_box(ra, leafBox, bvhData, Ra);
+        load_box(rb, leafBox, bvhData, Rb);
     }
     const int which = rt_pick_rotation(lInt, rInt, L, R, La, Lb, Ra, Rb);
-    float m[6];
-    if (which == 1) {            // L <-> R.left: R = (L, Rb)
+    float m[6], n2[6];
+    switch (which) {
+    case 1:                      // L <-> R.left: R = (L, Rb)
         left[i] = ra; left[r] = l;
-        rt_box_merge(L, Rb, m);
-    } else if (which == 2) {     // L <-> R.right: R = (Ra, L)
+        set_parent(parent, ra, i); set_parent(parent, l, r);
+        rt_box_merge(L, Rb, m); store_box(bvhData, r, m);
+        break;
+    case 2:                      // L <-> R.right: R = (Ra, L)
         left[i] = rb; right[r] = l;
-        rt_box_merge(Ra, L, m);
-    } else if (which == 3) {     // R <-> L.left: L = (R, Lb)
+        set_parent(parent, rb, i); set_parent(parent, l, r);
+        rt_box_merge(Ra, L, m); store_box(bvhData, r, m);
+        break;
+    case 3:                      // R <-> L.left: L = (R, Lb)
         right[i] = la; left[l] = r;
-        rt_box_merge(R, Lb, m);
-    } else if (which == 4) {     // R <-> L.right: L = (La, R)
+        set_parent(parent, la, i); set_parent(parent, r, l);
+        rt_box_merge(R, Lb, m); store_box(bvhData, l, m);
+        break;
+    case 4:                      // R <-> L.right: L = (La, R)
         right[i] = lb; right[l] = r;
-        rt_box_merge(La, R, m);
+        set_parent(parent, lb, i); set_parent(parent, r, l);
+        rt_box_merge(La, R, m); store_box(bvhData, l, m);
+        break;
+    case 5:                      // La <-> Ra: both children change
+        left[l] = ra; left[r] = la;
+        set_parent(parent, ra, l); set_parent(parent, la, r);
+        rt_box_merge(Ra, Lb, m); rt_box_merge(La, Rb, n2);
+        store_box(bvhData, l, m); store_box(bvhData, r, n2);
+        break;
+    case 6:                      // La <-> Rb
+        left[l] = rb; right[r] = la;
+        set_parent(parent, rb, l); set_parent(parent, la, r);
+        rt_box_merge(Rb, Lb, m); rt_box_merge(Ra, La, n2);
+        store_box(bvhData, l, m); store_box(bvhData, r, n2);
+        break;
+    default: break;
     }
-    if (which >= 1 && which <= 4) {
-        const uint32_t c = which <= 2 ? r : l;
-        bvhData[c * 2 + 0] = make_float4(m[0], m[1], m[2], 0.0f);
-        bvhData[c * 2 + 1] = make_float4(m[3], m[4], m[5], 0.0f);
-    } else if (which >= 5) {     // 5: La <-> Ra, 6: La <-> Rb: both children change
-        float n2[6];
-        if (which == 5) {
-            left[l] = ra; left[r] = la;
-            rt_box_merge(Ra, Lb, m); rt_box_merge(La, Rb, n2);
-        } else {
-            left[l] = rb; right[r] = la;
-            rt_box_merge(Rb, Lb, m); rt_box_merge(Ra, La, n2);
+}
+
+__global__ __launch_bounds__(256) void k_sweep(uint32_t nAll, const uint32_t *__restrict__ list, const uint32_t *__restrict__ listCount, uint32_t iter,
+                                                uint32_t nPasses, uint32_t *left, uint32_t *right, uint32_t *parent,
+                                                const float4 *__restrict__ leafBox, float4 *bvhData, uint32_t *prog)
+{
+    const uint32_t n = list ? *listCount : nAll;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const uint32_t i = list ? list[k] : k;
+        const uint32_t mine = prog[i];
+        if (SWEEP_PASSES(mine) >= nPasses) continue;
+        const uint32_t pass = SWEEP_PASSES(mine) + 1u;
+        const uint32_t l = left[i], r = right[i];
+        if (!(l & RT_LEAF_BIT) && !sweep_finished_before(prog[l], pass, iter)) continue;
+        if (!(r & RT_LEAF_BIT) && !sweep_finished_before(prog[r], pass, iter)) continue;
+        if (pass >= 3u) {
+            const uint32_t up = parent[i];
+            if (up != 0xFFFFFFFFu && !sweep_finished_before(prog[up], pass - 1u, iter)) continue;
         }
-        bvhData[l * 2 + 0] = make_float4(m[0], m[1], m[2], 0.0f);
-        bvhData[l * 2 + 1] = make_float4(m[3], m[4], m[5], 0.0f);
-        bvhData[r * 2 + 0] = make_float4(n2[0], n2[1], n2[2], 0.0f);
-        bvhData[r * 2 + 1] = make_float4(n2[3], n2[4], n2[5], 0.0f);
+        if (pass == 1u) {
+            float a[6], b[6], m[6];
+            load_box(l, leafBox, bvhData, a);
+            load_box(r, leafBox, bvhData, b);
+            rt_box_merge(a, b, m);
+            store_box(bvhData, i, m);
+        } else {
+            rotate_node(i, l, r, left, right, parent, leafBox, bvhData);
+        }
+        prog[i] = pass << 8 | iter;
     }
-    done[i] = iter;
+}
+
+// The nodes of a sweep that still have passes to take (the order of the list does not matter).
+__global__ __launch_bounds__(COMPACT_THREADS) void k_compact_sweep(uint32_t nAll, const uint32_t *__restrict__ listIn, const uint32_t *__restrict__ countIn,
+                                                                   const uint32_t *__restrict__ prog, uint32_t nPasses, uint32_t *__restrict__ listOut,
+                                                                   uint32_t *__restrict__ count)
+{
+    __shared__ uint32_t waveBase[COMPACT_THREADS / 64];
+    __shared__ uint32_t blockBase;
+    const uint32_t n = listIn ? *countIn : nAll;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t chunk = blockIdx.x * COMPACT_THREADS; chunk < n; chunk += gridDim.x * COMPACT_THREADS) {
+        const uint32_t k = chunk + threadIdx.x;
+        const uint32_t i = k < n ? (listIn ? listIn[k] : k) : 0u;
+        const bool keep = k < n && SWEEP_PASSES(prog[i]) < nPasses;
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) waveBase[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+            for (uint32_t w = 0; w < COMPACT_THREADS / 64; ++w) {
+                const uint32_t c = waveBase[w];
+                waveBase[w] = total;
+                total += c;
+            }
+            blockBase = total ? atomicAdd(count, total) : 0u;
+        }
+        __syncthreads();
+        if (keep) listOut[blockBase + waveBase[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
     }
+}
+
+// What the second half of the build derives from the scene's box (the root box of the reference's tree): made on
+// the device by one thread, so the host does not have to wait for that box in the middle of the build.
+struct BuildPlan {
+    RtKeyPlan keys;
+    RtQGrid grid;
+    RtAABB root;
+};
+
+__global__ void k_plan(const float4 *__restrict__ bvhData, BuildPlan *__restrict__ out)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const float4 mn = bvhData[0], mx = bvhData[1];
+    const float lo[3] = {mn.x, mn.y, mn.z}, hi[3] = {mx.x, mx.y, mx.z};
+    BuildPlan p;
+    p.keys = rt_key_plan(lo, hi);
+    p.grid = rt_qh_grid(lo, hi);
+    memset(&p.root, 0, sizeof p.root);
+    for (int a = 0; a < 3; ++a) {
+        p.root.min[a] = lo[a];
+        p.root.max[a] = hi[a];
+    }
+    *out = p;
 }
 
 // ------------------------------------------------------------------ half-float traversal nodes
 // The 32-byte node of a tree whose links and boxes are final: both child boxes rounded outward onto the
 // half-float planes of the root-box grid (rt_qh.h).  A plane the grid cannot cover raises the error flag.
-__global__ __launch_bounds__(256) void k_emit_qnodes(uint32_t N, RtQGrid g, const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
-                                                      const uint32_t *__restrict__ sortedIdx, const float4 *__restrict__ triAABB,
+__global__ __launch_bounds__(256) void k_emit_qnodes(uint32_t N, const BuildPlan *__restrict__ planPtr, const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
+                                                      const float4 *__restrict__ leafBox,
                                                       const float4 *__restrict__ bvhData, uint4 *__restrict__ qnodes, uint32_t *__restrict__ errorFlag)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N - 1) return;
+    const RtQGrid g = planPtr->grid;
     const uint32_t l = left[i], r = right[i];
     float a[6], b[6];
-    load_box(l, sortedIdx, triAABB, bvhData, a);
-    load_box(r, sortedIdx, triAABB, bvhData, b);
+    load_box(l, leafBox, bvhData, a);
+    load_box(r, leafBox, bvhData, b);
     uint32_t wl[3], wr[3];
     const bool okL = rt_qh_box(g, a, a + 3, wl);
     const bool okR = rt_qh_box(g, b, b + 3, wr);
@@ -582,11 +703,12 @@ __global__ void k_wire_triangles(uint32_t N, const uint32_t *__restrict__ idx, c
 // ------------------------------------------------------------------ the traversal tree's own keys and bookkeeping
 // Sort key of the tree the rays walk (include/rt_finekey.h): the centre of the triangle's box,
 // the same (min + max) * 0.5 as k_calculate, on a 29-bit grid over the scene's own box, under 2 bits for the size of the box.
-__global__ __launch_bounds__(256) void k_fine_keys(uint32_t N, const float4 *__restrict__ triAABB, RtKeyPlan plan,
+__global__ __launch_bounds__(256) void k_fine_keys(uint32_t N, const float4 *__restrict__ triAABB, const BuildPlan *__restrict__ planPtr,
                                                     uint32_t *__restrict__ keys, uint32_t *__restrict__ triIndex)
 {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= N) return;
+    const RtKeyPlan plan = planPtr->keys;
     const float4 mn = triAABB[id * 2], mx = triAABB[id * 2 + 1];
     const float lo[3] = {mn.x, mn.y, mn.z}, hi[3] = {mx.x, mx.y, mx.z};
     keys[id] = rt_fine_key(plan, lo, hi);
@@ -665,12 +787,15 @@ struct BuildScratch {
     uint32_t nbSort = 0, histLen = 0;
 };
 
-// One bottom-up pass over the NI internal nodes, a launch per tree level: launch(blocks, list, listCount, iter).
+// The bottom-up fit of the reference's tree, a launch per tree level: launch(blocks, list, listCount, iter).
 // From the third level on the launches run over a list of the nodes still to do, renewed every six levels; the
 // length of a list stays on the device (every compaction has a count word of its own in sc.counts, zeroed once per
 // build), the launches over it are grid-stride loops of a size the host only estimates, so no level waits for the
-// host.  PASS_LEVELS levels are launched whatever the tree's height (a Karras tree over unique 32-bit keys has at
-// most 32, a rotation pass can add one); the count of what is then still undone is looked at when the build ends.
+// host.  FIT_LEVELS levels are launched whatever the tree's height: along a root-to-leaf chain of a Karras tree
+// the common prefix of the unique 32-bit keys grows by at least a bit per node, so no chain has more than 32
+// internal nodes.  The sweep of the other tree (run_sweep) gets PASS_LEVELS, room for the levels its rotations
+// may add; the count of what either leaves undone is looked at when the build ends.
+#define FIT_LEVELS 34u
 #define PASS_LEVELS 50u
 #define PASS_COUNT_WORDS 256u
 template <class Launch>
@@ -681,7 +806,7 @@ static int run_levels(RtContext *ctx, BuildScratch &sc, uint32_t NI, Launch laun
     const uint32_t *list = nullptr, *listCount = nullptr;
     uint32_t expected = NI;       // a guess at the list's length, for the size of the launches only
     int which = 0;
-    for (uint32_t iter = 0; iter < PASS_LEVELS; ++iter) {
+    for (uint32_t iter = 0; iter < FIT_LEVELS; ++iter) {
         const uint32_t blocks = list ? (expected + 255u) / 256u : (NI + 255u) / 256u;
         launch(blocks < 64u ? 64u : blocks, list, listCount, iter);
         if (iter == 2 || (iter > 2 && (iter - 2) % 6 == 0)) {
@@ -705,11 +830,57 @@ static int run_levels(RtContext *ctx, BuildScratch &sc, uint32_t NI, Launch laun
     return RT_OK;
 }
 
+// The sweep of k_sweep over the NI internal nodes: nPasses passes, launches 1 .. PASS_LEVELS + what the passes add.
+// The nodes at the bottom finish their last pass in launch `firstFinish`, and from there on half of what is left
+// finishes with every launch: the launches then run over a list of the unfinished nodes, renewed after every launch
+// at first and less often as it shrinks.  As in run_levels the list lengths stay on the device.
+static int run_sweep(RtContext *ctx, BuildScratch &sc, uint32_t NI, uint32_t nPasses, uint32_t *left, uint32_t *right, uint32_t *parent,
+                     const float4 *leafBox, RtAABB *bvhData)
+{
+    hipStream_t st = ctx->stream;
+    RT_HIP(ctx, hipMemsetAsync(sc.done, 0, (size_t)NI * 4, st));
+    const uint32_t firstFinish = nPasses >= 3u ? 2u * nPasses - 2u : nPasses;
+    const uint32_t last = PASS_LEVELS + firstFinish;
+    if (last > SWEEP_MAX_LAUNCH) return rt_fail(ctx, RT_E_STATE, "BVH build: too many passes for one sweep");
+    const uint32_t *list = nullptr, *listCount = nullptr;
+    uint32_t expected = NI, nextCompact = firstFinish, compactions = 0;
+    int which = 0;
+    for (uint32_t iter = 1; iter <= last; ++iter) {
+        const uint32_t blocks = ((list ? expected : NI) + 255u) / 256u;
+        rt_timer_begin(ctx, "k_sweep");
+        hipLaunchKernelGGL(k_sweep, dim3(blocks < 64u ? 64u : blocks), dim3(256), 0, st, NI, list, listCount, iter, nPasses, left, right, parent, leafBox,
+                           (float4 *)bvhData, sc.done);
+        rt_timer_end(ctx);
+        if (iter == nextCompact && iter < last) {
+            if (sc.nextCount >= PASS_COUNT_WORDS) return rt_fail(ctx, RT_E_STATE, "BVH build: out of count words");
+            uint32_t *count = sc.counts + sc.nextCount++;
+            const uint32_t cblocks = ((list ? expected : NI) + COMPACT_THREADS - 1) / COMPACT_THREADS;
+            hipLaunchKernelGGL(k_compact_sweep, dim3(cblocks < 16u ? 16u : cblocks), dim3(COMPACT_THREADS), 0, st, NI, list, listCount, sc.done, nPasses,
+                               sc.undone[which], count);
+            list = sc.undone[which];
+            listCount = count;
+            which ^= 1;
+            compactions += 1;
+            // a guess from above (blocks that find nothing to do cost next to nothing, too few blocks cost a lot): a balanced
+            // tree would halve the list with every launch, a Karras tree has more tall nodes than that
+            const uint32_t shrink = (iter - firstFinish + 1u) * 2u / 3u;
+            expected = shrink < 20u ? NI >> shrink : 0u;
+            if (expected < 65536u) expected = 65536u;
+            nextCompact += compactions < 5u ? 1u : (compactions < 9u ? 2u : 6u);
+        }
+    }
+    if (sc.nFinal >= 32 || sc.nextCount >= PASS_COUNT_WORDS) return rt_fail(ctx, RT_E_STATE, "BVH build: too many passes");
+    uint32_t *count = sc.counts + sc.nextCount++;
+    hipLaunchKernelGGL(k_compact_sweep, dim3(16), dim3(COMPACT_THREADS), 0, st, NI, list, listCount, sc.done, nPasses, sc.undone[which], count);
+    sc.finalCount[sc.nFinal++] = (uint32_t)(count - sc.counts);
+    return RT_OK;
+}
+
 // sort -> duplicate-key spreading -> Karras tree -> bottom-up fit, on keys already in keysRaw / ids in sortedIdx.
 // Outputs: keysRaw (sorted), sortedIdx, codes (unique), left/right/parent/leafParent, bvhData, nodes (exact 64-byte nodes).
 static int build_tree_from_keys(RtContext *ctx, BuildScratch &sc, uint32_t N, uint32_t *keysRaw, uint32_t *sortedIdx, uint32_t *codes,
                                 uint32_t *left, uint32_t *right, uint32_t *parent, uint32_t *leafParent, uint32_t *rangeSize,
-                                RtAABB *bvhData, RtNode64 *nodes)
+                                RtAABB *bvhData, RtNode64 *nodes, bool fit = true)
 {
     hipStream_t st = ctx->stream;
     const uint32_t NI = N - 1;
@@ -739,6 +910,7 @@ static int build_tree_from_keys(RtContext *ctx, BuildScratch &sc, uint32_t N, ui
     rt_timer_begin(ctx, "k_tree");
     hipLaunchKernelGGL(k_tree, gridNI, blk, 0, st, codes, N, left, right, parent, leafParent, rangeSize);
     rt_timer_end(ctx);
+    if (!fit) return RT_OK;
     return run_levels(ctx, sc, NI, [&](uint32_t blocks, const uint32_t *list, const uint32_t *listCount, uint32_t iter) {
         rt_timer_begin(ctx, "k_fit");
         hipLaunchKernelGGL(k_fit, dim3(blocks), blk, 0, st, NI, list, listCount, iter, left, right, sortedIdx, (const float4 *)ctx->dTriAABB,
@@ -765,7 +937,11 @@ int rt_build_impl(RtContext *ctx)
     uint32_t *wKeys = nullptr, *wCodes = nullptr, *wSortedIdx = nullptr, *wLeft = nullptr, *wRight = nullptr, *wParent = nullptr,
              *wLeafParent = nullptr, *refSize = nullptr, *walkLeafOfTri = nullptr;
     RtAABB *wBvhData = nullptr;
+    BuildPlan *plan = nullptr;
+    float4 *wLeafBox = nullptr;
 
+    RT_HIP(ctx, dalloc(&plan, 1));
+    RT_HIP(ctx, dalloc(&wLeafBox, (size_t)N * 2));
     RT_HIP(ctx, dalloc(&ctx->dTriAABB, (size_t)N));
     RT_HIP(ctx, dalloc(&ctx->dMortonUnsorted, (size_t)N));
     RT_HIP(ctx, dalloc(&ctx->dMortonSortedRaw, (size_t)N));
@@ -823,31 +999,18 @@ int rt_build_impl(RtContext *ctx)
         return rc;
 
     if (N >= 2) {
-        RT_HIP(ctx, hipMemcpyAsync(&ctx->rootBox, ctx->dBvhData, sizeof(RtAABB), hipMemcpyDeviceToHost, st));
-        RT_HIP(ctx, hipStreamSynchronize(st));
-        ctx->grid = rt_qh_grid(ctx->rootBox.min, ctx->rootBox.max);
-
         // ---- the tree the rays walk: same pipeline, keys on a fine grid over the scene's own box
-        const RtKeyPlan plan = rt_key_plan(ctx->rootBox.min, ctx->rootBox.max);
+        hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, st, (const float4 *)ctx->dBvhData, plan);
         rt_timer_begin(ctx, "k_fine_keys");
         hipLaunchKernelGGL(k_fine_keys, gridN, blk, 0, st, N, (const float4 *)ctx->dTriAABB, plan, wKeys, wSortedIdx);
         rt_timer_end(ctx);
-        if ((rc = build_tree_from_keys(ctx, sc, N, wKeys, wSortedIdx, wCodes, wLeft, wRight, wParent, wLeafParent, nullptr, wBvhData, nullptr)))
+        if ((rc = build_tree_from_keys(ctx, sc, N, wKeys, wSortedIdx, wCodes, wLeft, wRight, wParent, wLeafParent, nullptr, wBvhData, nullptr, false)))
             return rc;
-        if (N >= 3) {
-            for (int pass = 0; pass < RT_ROTATION_PASSES; ++pass) {
-                // a rotation can lengthen a path by one level, so the height is no longer bounded by the key width
-                rc = run_levels(ctx, sc, NI, [&](uint32_t blocks, const uint32_t *list, const uint32_t *listCount, uint32_t iter) {
-                    rt_timer_begin(ctx, "k_rotate");
-                    hipLaunchKernelGGL(k_rotate, dim3(blocks), blk, 0, st, NI, list, listCount, iter, wLeft, wRight, wSortedIdx,
-                                       (const float4 *)ctx->dTriAABB, (float4 *)wBvhData, sc.done);
-                    rt_timer_end(ctx);
-                });
-                if (rc) return rc;
-            }
-        }
+        // its boxes and the rotation passes (a rotation can lengthen a path by a level: PASS_LEVELS leaves room for that)
+        hipLaunchKernelGGL(k_gather_leaf_boxes, gridN, blk, 0, st, N, wSortedIdx, (const float4 *)ctx->dTriAABB, wLeafBox);
+        if ((rc = run_sweep(ctx, sc, NI, N >= 3 ? 1u + RT_ROTATION_PASSES : 1u, wLeft, wRight, wParent, wLeafBox, wBvhData))) return rc;
         rt_timer_begin(ctx, "k_emit_qnodes");
-        hipLaunchKernelGGL(k_emit_qnodes, gridNI, blk, 0, st, N, ctx->grid, wLeft, wRight, wSortedIdx, (const float4 *)ctx->dTriAABB,
+        hipLaunchKernelGGL(k_emit_qnodes, gridNI, blk, 0, st, N, plan, wLeft, wRight, wLeafBox,
                            (const float4 *)wBvhData, (uint4 *)ctx->dQNodes, ctx->dErrorFlag);
         rt_timer_end(ctx);
         rt_timer_begin(ctx, "k_pack_leaves");
@@ -872,19 +1035,25 @@ int rt_build_impl(RtContext *ctx)
 
     RT_HIP(ctx, hipEventRecord(e1, st));
     uint32_t hostCounts[PASS_COUNT_WORDS];
+    BuildPlan hostPlan;
     RT_HIP(ctx, hipMemcpyAsync(hostCounts, sc.counts, sizeof hostCounts, hipMemcpyDeviceToHost, st));
+    if (N >= 2) RT_HIP(ctx, hipMemcpyAsync(&hostPlan, plan, sizeof hostPlan, hipMemcpyDeviceToHost, st));
     RT_HIP(ctx, hipStreamSynchronize(st));
+    if (N >= 2) {
+        ctx->rootBox = hostPlan.root;
+        ctx->grid = hostPlan.grid;
+    }
     RT_HIP(ctx, hipGetLastError());
     for (uint32_t k = 0; k < sc.nFinal; ++k)
         if (hostCounts[sc.finalCount[k]] != 0u)
-            return rt_fail(ctx, RT_E_STATE, "BVH build: %u nodes of a bottom-up pass were still undone after %u levels", hostCounts[sc.finalCount[k]], PASS_LEVELS);
+            return rt_fail(ctx, RT_E_STATE, "BVH build: %u nodes were still unfinished after the %u / %u levels a bottom-up pass is given", hostCounts[sc.finalCount[k]], FIT_LEVELS, PASS_LEVELS);
     float ms = 0;
     RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
     ctx->buildMs = ms;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     void *scratch[] = {sc.keysB, sc.valsB, sc.blockHist, sc.scanSums, sc.done, sc.undone[0], sc.undone[1], sc.counts, wKeys, wCodes, wSortedIdx, wLeft, wRight, wParent,
-                       wLeafParent, refSize, walkLeafOfTri, wBvhData};
+                       wLeafParent, refSize, walkLeafOfTri, wBvhData, plan, wLeafBox};
     for (void *q : scratch) (void)hipFree(q);
     ctx->built = true;
     return RT_OK;

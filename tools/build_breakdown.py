@@ -1,26 +1,24 @@
 #!/usr/bin/env python3
-"""Per-kernel device time of rt_bvh_build on the triangle soup.  Usage: build_breakdown.py [n_triangles]"""
-import json
-import os
+"""Per-kernel totals of the LAST rt_bvh_build in a rocprofv3 kernel trace made of tools/build_trace.py.
+Usage: build_breakdown.py <kernel_trace.csv>"""
+import csv
 import sys
+from collections import defaultdict
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from raytracing_amd import native, scenes  # noqa: E402
-
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
-sc = scenes.triangle_soup(n, seed=5, width=64, height=64)
-core = native.RtCore(0)
-core.upload(sc)
-core.bvh_build()                      # warm-up (allocations)
-core.enable_kernel_timing(True)
-reps = 3
-core.reset_stats()
-tot = 0.0
-for _ in range(reps):
-    core.bvh_build()
-    tot += core.stats()["buildMs"]
-out = {"n": n, "build_ms": round(tot / reps, 3), "mtris_per_s": round(n / (tot / reps) / 1e3, 1)}
-for k in ("k_calculate", "k_sort_hist", "k_sort_scatter", "k_scan", "k_dedup", "k_tree", "k_fit", "k_rotate", "k_emit_nodes", "k_fine_keys", "k_quantise", "k_pack_leaves", "k_visit_rank"):
-    ms, cnt = core.kernel_time(k)
-    out[k] = {"ms": round(ms / reps, 3), "launches": cnt // reps}
-print(json.dumps(out))
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+starts = [i for i, r in enumerate(rows) if "k_calculate" in r["Kernel_Name"]]
+marker = rows[starts[0]]["Kernel_Name"] if starts else None
+firsts = [i for i in starts if rows[i]["Kernel_Name"] == marker]
+rows = rows[firsts[-1]:]
+t0, t1 = int(rows[0]["Start_Timestamp"]), max(int(r["End_Timestamp"]) for r in rows)
+tot, cnt = defaultdict(float), defaultdict(int)
+busy = 0.0
+for r in rows:
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    name = r["Kernel_Name"].split("(")[0][:48]
+    tot[name] += d
+    cnt[name] += 1
+    busy += d
+print(f"span {(t1 - t0) / 1e6:.3f} ms, kernels {busy:.3f} ms in {len(rows)} launches")
+for name in sorted(tot, key=tot.get, reverse=True):
+    print(f"{tot[name]:9.3f} ms {cnt[name]:5d}  {name}")
