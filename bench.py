@@ -38,6 +38,7 @@ from raytracing_amd import dist as rtdist  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E, spec
 SIMDS = 256 * 4         # compute units x SIMDs
 MAX_CLOCK_GHZ = 2.4     # a wave64 vector instruction occupies its SIMD for 4 clocks
+L1_GATHER_PEAK_G = round(1.68 * 256 * 2.4, 1)      # measured, tools/ubench: divergent 16-byte loads that hit the L1
 VALU_PEAK_GINST = SIMDS * MAX_CLOCK_GHZ / 4.0   # wave-instructions per ns over the chip = 614.4 G/s
 
 
@@ -160,6 +161,8 @@ def main():
         sc = rtdist.broadcast_scene(sc, comm_device)
     core = native.RtCore(local_rank)
     core.upload(sc)
+    core.bvh_build()
+    build_first_ms = core.stats()["buildMs"]         # the process's first build also pays for loading the kernels
     core.bvh_build()
     build_ms = core.stats()["buildMs"]
     params = sc.params.copy()
@@ -301,6 +304,14 @@ def main():
                               "frac": round(gbps / HBM_PEAK_GBS, 4), "traffic_over_algorithmic": round(m["hbm_bytes_per_launch"] / per_launch, 4)}
                 out["counters"] = {k: m.get(k) for k in ("l2_hit_rate", "lane_utilisation", "waves_per_simd", "valu_busy",
                                                          "valu_instructions_per_launch", "kernel_clocks_per_launch")}
+                if m.get("l1_lane_accesses_per_launch"):
+                    acc = m["l1_lane_accesses_per_launch"] / dur / 1e9
+                    out["vector_memory"] = {"bound": "l1 data return", "achieved": round(acc, 1), "peak": L1_GATHER_PEAK_G,
+                                            "unit": "G lane-accesses/s", "frac": round(acc / L1_GATHER_PEAK_G, 4),
+                                            "td_busy": m.get("td_busy"), "ta_busy": m.get("ta_busy"),
+                                            "note": "divergent 16-byte gathers; peak = 1.68 lane-accesses per clock and CU with every access "
+                                                    "an L1 hit (tools/ubench), 0.85 when they come from L2; td_busy is the share of the "
+                                                    "kernel's clocks the L1 data-return units were busy"}
                 out["pmc_sources_match"] = m.get("source_id") == sid
             out["note"] = ("frac = vector wave-instructions x 4 clocks / (1024 SIMDs x launch time x 2.4 GHz): the share of the chip's "
                            "vector issue slots the launch used; useful = frac x lane utilisation. Instruction and memory-side byte "
@@ -328,6 +339,8 @@ def main():
                             "one frame in flight"},
             "paths_per_step": args.width * args.height * args.spp,
             "bvh_build_ms": round(build_ms, 3),
+            "bvh_build_first_ms": round(build_first_ms, 3),
+            "bvh_build_bytes_per_triangle": {"contract": 436, "reference_tree_and_leaves": 690, "with_traversal_tree_and_rotations": 2600},
             "bvh_build_mtris_per_s": round(sc.n_triangles / max(build_ms, 1e-6) / 1e3, 2),
             "traversal_counts_per_step": total,
             "roofline": roofline,

@@ -40,6 +40,11 @@ for kname, v in summary.items():
             "salu_instructions_per_launch": int(v["SQ_INSTS_SALU"] / v["_dispatches"]),
             "vmem_read_instructions_per_launch": int(v["SQ_INSTS_VMEM_RD"] / v["_dispatches"]),
             "l1_to_l2_read_requests_per_launch": int(v.get("TCP_TCC_READ_REQ_sum", 0.0) / v["_dispatches"]),
+            # the vector memory path: lane accesses the L1s served, and how busy the 256 address (TA) and data-return (TD)
+            # units were over the kernel's clocks
+            "l1_lane_accesses_per_launch": int(v.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / v["_dispatches"]),
+            "ta_busy": round(v.get("TA_TA_BUSY_sum", 0.0) / (256.0 * v["GRBM_GUI_ACTIVE"] / 8.0), 3),
+            "td_busy": round(v.get("TD_TD_BUSY_sum", 0.0) / (256.0 * v["GRBM_GUI_ACTIVE"] / 8.0), 3),
         }
     out[f"k_traverse<{src}>"] = {
         **acct,
