@@ -36,27 +36,34 @@ class RtError(RuntimeError):
         self.code = code
 
 
-def load():
-    """Load librtcore.so; raises if it has not been built (python __graft_entry__.py build)."""
+def _open(path):
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} is missing: build it with `make -C raytracing_amd/csrc`")
+    # One HIP runtime per process: the torch wheel carries its own libamdhip64 (soname libamdhip64.so.7, file
+    # name libamdhip64.so).  Loaded first, it also satisfies librtcore's libamdhip64.so.7; loaded second, the
+    # loader takes it for a different library, and the second runtime in a process finds no devices.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = C.CDLL(path)
+    lib.rt_last_error.restype = C.c_char_p
+    lib.rt_version.restype = C.c_char_p
+    lib.rt_sample_count.restype = C.c_uint32
+    lib.rt_local_pixel_count.restype = C.c_uint32
+    for name in EXPORTS:
+        getattr(lib, name)
+    return lib
+
+
+def load(path=None):
+    """Load librtcore.so (or another build of it at `path`); raises if it has not been built
+    (python __graft_entry__.py build)."""
     global _lib
+    if path is not None:
+        return _open(path)
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise FileNotFoundError(f"{LIB_PATH} is missing: build it with `make -C raytracing_amd/csrc`")
-        # One HIP runtime per process: the torch wheel carries its own libamdhip64 (soname libamdhip64.so.7, file
-        # name libamdhip64.so).  Loaded first, it also satisfies librtcore's libamdhip64.so.7; loaded second, the
-        # loader takes it for a different library, and the second runtime in a process finds no devices.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
-        lib = C.CDLL(LIB_PATH)
-        lib.rt_last_error.restype = C.c_char_p
-        lib.rt_version.restype = C.c_char_p
-        lib.rt_sample_count.restype = C.c_uint32
-        lib.rt_local_pixel_count.restype = C.c_uint32
-        for name in EXPORTS:
-            getattr(lib, name)
-        _lib = lib
+        _lib = _open(LIB_PATH)
     return _lib
 
 
@@ -67,8 +74,8 @@ def _p(a):
 class RtCore:
     """One context = one GPU (rt_create .. rt_destroy)."""
 
-    def __init__(self, device_id=0):
-        self.lib = load()
+    def __init__(self, device_id=0, lib_path=None):
+        self.lib = load(lib_path)
         self.ctx = C.c_void_p()
         rc = self.lib.rt_create(C.c_int(device_id), C.byref(self.ctx))
         if rc != 0:

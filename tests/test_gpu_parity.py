@@ -500,6 +500,63 @@ def test_shadowmap_pass_started_by_dispatch_gives_the_same_bits(core):
         core.set_option(wire.OPT_EAGER_SHADOWMAP, 1)
 
 
+def test_spilled_stacks_of_concurrent_launches_do_not_meet(core):
+    """A build of the library that keeps two stack levels per lane in LDS instead of sixteen sends nearly every
+    ray's stack through the spill areas in device memory.  Launches that run at the same time -- the shadow rays
+    under the bounces, the two streams of RT_OPT_TWO_STREAMS, the static-scratch query -- must each have an area
+    of their own: the images are the ordinary library's, bit for bit, in every schedule."""
+    import os
+    import torch
+    from raytracing_amd import native
+    path = os.path.join(os.path.dirname(native.LIB_PATH), "librtcore_spill2.so")
+    if not os.path.exists(path):
+        pytest.skip("librtcore_spill2.so has not been built")
+    sc = scenes.car_standin(192, 128, detail=0.08)
+    seeds = scenes.frame_seeds(4, seed=21)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(sc.params)
+    core.set_dirty()
+    core.render_frames(seeds)
+    want = [core.readback(w) for w in (wire.IMAGE_RT, wire.IMAGE_SHADOWMAP, wire.IMAGE_CONVERGED)]
+    o, d = H.camera_rays(sc.params, 64)
+    want_hits = core.trace_rays(o, d)
+
+    spill = native.RtCore(0, lib_path=path)
+    try:
+        spill.upload(sc)
+        spill.bvh_build()
+        spill.set_params(sc.params)
+        for name, options in (("shadow rays under the bounces", {}),
+                              ("plain order", {wire.OPT_OVERLAP_SHADOW: 0}),
+                              ("two streams", {wire.OPT_TWO_STREAMS: 1})):
+            for k in (wire.OPT_OVERLAP_SHADOW, wire.OPT_TWO_STREAMS):
+                spill.set_option(k, {wire.OPT_OVERLAP_SHADOW: 1, wire.OPT_TWO_STREAMS: 0}[k])
+            for k, v in options.items():
+                spill.set_option(k, v)
+            spill.set_dirty()
+            spill.render_frames(seeds)
+            for label, which, ref in zip(("rt", "shadow map", "converged"), (wire.IMAGE_RT, wire.IMAGE_SHADOWMAP, wire.IMAGE_CONVERGED), want):
+                H.assert_bits_equal(spill.readback(which), ref, f"{label}, stacks spilled, {name}")
+        got = spill.trace_rays(o, d)
+        for k in ("triangle", "t", "u", "v"):
+            H.assert_bits_equal(got[k], want_hits[k], f"{k}: stacks spilled, rt_trace_rays")
+        # the query that allocates nothing spills into its static array
+        n = len(o)
+        o4 = np.zeros((n, 4), np.float32); o4[:, :3] = o
+        d4 = np.zeros((n, 4), np.float32); d4[:, :3] = d
+        to, td = torch.from_numpy(o4).cuda(), torch.from_numpy(d4).cuda()
+        a = torch.full((n, 4), -1.0, dtype=torch.float32, device="cuda")
+        b = torch.full((n, 4), -2.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        spill.trace_rays_device(to.data_ptr(), td.data_ptr(), n, a.data_ptr())
+        spill.trace_rays_device_static(to.data_ptr(), td.data_ptr(), n, b.data_ptr())
+        spill.synchronize()
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    finally:
+        spill.close()
+
+
 def test_resume_from_uploaded_accumulator(core):
     sc = scenes.cornell_box(64, 64, sphere_segments=16)
     seeds = scenes.frame_seeds(4, seed=8)
