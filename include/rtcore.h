@@ -32,7 +32,8 @@ extern "C" {
 #define RT_E_DEVICE    (-2)  /* HIP runtime error (no GPU, launch failure, ...) */
 #define RT_E_NOMEM     (-3)
 #define RT_E_STATE     (-4)  /* e.g. dispatch before rt_bvh_build */
-#define RT_E_OVERFLOW  (-5)  /* traversal stack overflow flagged by a kernel */
+#define RT_E_OVERFLOW  (-5)  /* the packet walker (RT_OPT_PACKET_*) ran out of stack; the default walker cannot: a ray whose
+                                 stack is full starts over on a walk that needs none */
 
 /* ------------------------------------------------- wire structs (blittable) */
 /* Assets/Shaders/BVH/Constants.cginc:11-17, Assets/Scripts/BVH/SceneDataTypes.cs:6-21 */

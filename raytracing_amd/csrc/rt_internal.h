@@ -17,7 +17,9 @@
 
 #define RT_LEAF_BIT 0x80000000u
 #define RT_INVALID 0xFFFFFFFFu
-#define RT_STACK_DEPTH 32   // Karras tree over unique 32-bit keys: depth <= 32
+#ifndef RT_STACK_DEPTH
+#define RT_STACK_DEPTH 32   // stack levels of a ray (16 in LDS, the rest in a spill area); a ray that needs more starts over on the stackless walk
+#endif
 
 // ---- traversal layouts (HBM) ----------------------------------------------
 // One internal node, 64 B, holding BOTH children's boxes so that a visit costs

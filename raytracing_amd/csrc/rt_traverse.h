@@ -61,6 +61,7 @@
 #define TRV_WALK_DEN 4u         // have nodes to visit can go on (the rest wait for triangle tests)
 #endif
 #define TRV_DONE 0xFFFFFFFFu
+#define TRV_REDO 0xFFFFFFFEu    // in WalkState::tos of a lane whose node is TRV_DONE: this ray takes the exact, stackless walk next
 #define TRV_LDS_WORDS ((TRV_STACK_LDS + TRV_PEND_CAP) * TRV_THREADS)
 static_assert(TRV_LDS_WORDS * 4 * 6 <= 160 * 1024, "six blocks per CU must fit the LDS");
 #define TRV_BLOCKS_PER_CU 8u    // blocks launched per CU; five are resident at a time (88-96 registers per lane, 26 KB of LDS per
@@ -347,11 +348,14 @@ __device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySla
                         spill[(size_t)(w.sp - TRV_STACK_LDS) * spillLanes] = l;
                         w.sp++;
                         w.tos = l;
-                    } else {                                         // deeper than the spill area
-                        *sv.errorFlag = 1u;
+                    } else {
+                        // Deeper than the stack (rotations may lengthen a path of the tree past the 32 levels a Karras
+                        // tree has): the ray starts over on the reference's tree with the walk that needs no stack
+                        // and returns the same hit.
                         w.node = TRV_DONE;
                         w.sp = 1;
-                        w.tos = TRV_DONE;
+                        w.tos = TRV_REDO;
+                        w.npend = 0;
                     }
                 } else if (!(goL || goR)) {
                     w.node = w.tos;
@@ -423,8 +427,7 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                 w.node = TRV_DONE;
                 if (COUNT) nRays++;
                 if (__builtin_expect(rt_ray_needs_exact_walk(o, d) || !rt_slab_finite(slab), 0)) {
-                    exact_walk<COUNT>(sv, o, d, r, h, cnt);    // the whole walk, now; retired below
-                    firstHit = 2u;
+                    w.tos = TRV_REDO;                          // the whole walk at once, after the node phase; retired below
                 } else if (sv.nTriangles != 0) {
                     if (COUNT) cnt[0]++;
                     const RtAABB &rb = sv.rootBox;
@@ -456,6 +459,16 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
             case 7: node_phase<7, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
             default: node_phase<8, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
             }
+        }
+
+        // ---- rays that do not fit the fast walk (a direction component that is zero or not finite, a slab the
+        //      half-float test cannot bound, a stack that ran out) take the reference's own walk, whole
+        if (__builtin_expect(hasRay && w.node == TRV_DONE && w.tos == TRV_REDO, 0)) {
+            h.t = rt_inf(); h.u = 0.0f; h.v = 0.0f; h.leaf = RT_INVALID;
+            exact_walk<COUNT>(sv, o, d, r, h, cnt);
+            firstHit = 2u;
+            w.tos = TRV_DONE;
+            w.npend = 0;
         }
 
         TRV_PHASE(1)
