@@ -394,9 +394,10 @@ int rt_render_frames(RtContext *ctx, const float *seeds, uint32_t n_frames)
     int rc = ready_to_render(ctx, true, ctx->paramsSet && (ctx->params.flags & RT_FLAG_MATTE_MASK) != 0);
     if (rc) return rc;
     if (n_frames && !seeds) return rt_fail(ctx, RT_E_INVALID, "null seeds");
+    RtArena arena(ctx->stream);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    RT_HIP(ctx, hipEventCreate(&e0));
-    RT_HIP(ctx, hipEventCreate(&e1));
+    RT_HIP(ctx, arena.event(&e0));
+    RT_HIP(ctx, arena.event(&e1));
     RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
     if ((rc = rt_render_frames_impl(ctx, seeds, n_frames))) return rc;
     RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
@@ -404,8 +405,6 @@ int rt_render_frames(RtContext *ctx, const float *seeds, uint32_t n_frames)
     float ms = 0;
     RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
     ctx->renderMs = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     rt_timer_resolve(ctx);
     return check_error_flag(ctx);
 }
@@ -445,8 +444,8 @@ int rt_readback(RtContext *ctx, int which, float *dst_rgba)
     if (!src) return rt_fail(ctx, RT_E_INVALID, "bad image selector %d", which);
     const size_t px = (size_t)ctx->params.width * ctx->params.height;
     float4 *full = nullptr;
-    RT_HIP(ctx, hipMalloc((void **)&full, px * sizeof(float4)));
-    struct Release { float4 *p; ~Release() { (void)hipFree(p); } } release{full};      // also on the early returns below
+    RtArena arena(ctx->stream);
+    RT_HIP(ctx, arena.alloc(&full, px));
     RT_HIP(ctx, hipMemsetAsync(full, 0, px * sizeof(float4), ctx->stream));
     int rc = rt_expand_local_impl(ctx, src, full);
     if (rc) return rc;
@@ -519,9 +518,10 @@ int rt_trace_rays_device(RtContext *ctx, const void *device_origins4, const void
     RT_ENTER_CHANGING(ctx);
     if (!ctx->built) return rt_fail(ctx, RT_E_STATE, "rt_bvh_build has not been called");
     if (n && (!device_origins4 || !device_dirs4 || !device_hits4)) return rt_fail(ctx, RT_E_INVALID, "null ray buffers");
+    RtArena arena(ctx->stream);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    RT_HIP(ctx, hipEventCreate(&e0));
-    RT_HIP(ctx, hipEventCreate(&e1));
+    RT_HIP(ctx, arena.event(&e0));
+    RT_HIP(ctx, arena.event(&e1));
     RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
     int rc = rt_trace_device_impl(ctx, (const float4 *)device_origins4, (const float4 *)device_dirs4, n, (RtHitRec *)device_hits4);
     if (rc) return rc;
@@ -530,8 +530,6 @@ int rt_trace_rays_device(RtContext *ctx, const void *device_origins4, const void
     float ms = 0;
     RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
     ctx->renderMs = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     rt_timer_resolve(ctx);
     return check_error_flag(ctx);
 }
@@ -557,10 +555,11 @@ int rt_trace_rays(RtContext *ctx, const float *origins, const float *directions,
     float4 *d4 = nullptr;      // [o4(n) | d4(n)]
     RtHitRec *dh = nullptr;
     float *dout = nullptr;     // [t | tri | u | v] x n
-    RT_HIP(ctx, hipMalloc((void **)&d3, (size_t)n * 6 * 4));
-    RT_HIP(ctx, hipMalloc((void **)&d4, (size_t)n * 2 * sizeof(float4)));
-    RT_HIP(ctx, hipMalloc((void **)&dh, (size_t)n * sizeof(RtHitRec)));
-    RT_HIP(ctx, hipMalloc((void **)&dout, (size_t)n * 16));
+    RtArena arena(ctx->stream);
+    RT_HIP(ctx, arena.alloc(&d3, (size_t)n * 6));
+    RT_HIP(ctx, arena.alloc(&d4, (size_t)n * 2));
+    RT_HIP(ctx, arena.alloc(&dh, (size_t)n));
+    RT_HIP(ctx, arena.alloc(&dout, (size_t)n * 4));
     RT_HIP(ctx, hipMemcpyAsync(d3, origins, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
     RT_HIP(ctx, hipMemcpyAsync(d3 + (size_t)3 * n, directions, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
     int rc = rt_pack_rays_impl(ctx, d3, d3 + (size_t)3 * n, n, d4, d4 + n);
@@ -572,10 +571,6 @@ int rt_trace_rays(RtContext *ctx, const float *origins, const float *directions,
     if (out_u) RT_HIP(ctx, hipMemcpyAsync(out_u, dout + (size_t)2 * n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (out_v) RT_HIP(ctx, hipMemcpyAsync(out_v, dout + (size_t)3 * n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(d3);
-    (void)hipFree(d4);
-    (void)hipFree(dh);
-    (void)hipFree(dout);
     rt_timer_resolve(ctx);
     return check_error_flag(ctx);
 }
@@ -586,18 +581,16 @@ int rt_debug_eval(RtContext *ctx, int which, const float *x, const float *y, uin
     if (!x || !y || !out || n == 0) return rt_fail(ctx, RT_E_INVALID, "bad rt_debug_eval arguments");
     const uint32_t nin = which == 7 ? 2u : (which == 8 ? 15u : n);
     float *dx = nullptr, *dy = nullptr, *dout = nullptr;
-    RT_HIP(ctx, hipMalloc((void **)&dx, (size_t)nin * 4));
-    RT_HIP(ctx, hipMalloc((void **)&dy, (size_t)nin * 4));
-    RT_HIP(ctx, hipMalloc((void **)&dout, (size_t)n * 4));
+    RtArena arena(ctx->stream);
+    RT_HIP(ctx, arena.alloc(&dx, (size_t)nin));
+    RT_HIP(ctx, arena.alloc(&dy, (size_t)nin));
+    RT_HIP(ctx, arena.alloc(&dout, (size_t)n));
     RT_HIP(ctx, hipMemcpyAsync(dx, x, (size_t)nin * 4, hipMemcpyHostToDevice, ctx->stream));
     RT_HIP(ctx, hipMemcpyAsync(dy, y, (size_t)(which == 7 || which == 8 ? 1 : nin) * 4, hipMemcpyHostToDevice, ctx->stream));
     int rc = rt_debug_eval_impl(ctx, which, dx, dy, n, dout);
     if (rc) return rc;
     RT_HIP(ctx, hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(dx);
-    (void)hipFree(dy);
-    (void)hipFree(dout);
     return RT_OK;
 }
 

@@ -138,9 +138,10 @@ extern "C" int rt_trace_primitives(RtContext *ctx, const float *origins, const f
     if (!origins || !directions) return rt_fail(ctx, RT_E_INVALID, "null rays");
     float *d3 = nullptr, *dout = nullptr;   // dout: [t | primitive | normal(3)] x n
     float4 *d4 = nullptr;
-    RT_HIP(ctx, hipMalloc((void **)&d3, (size_t)n * 6 * 4));
-    RT_HIP(ctx, hipMalloc((void **)&d4, (size_t)n * 2 * sizeof(float4)));
-    RT_HIP(ctx, hipMalloc((void **)&dout, (size_t)n * 5 * 4));
+    RtArena arena(ctx->stream);
+    RT_HIP(ctx, arena.alloc(&d3, (size_t)n * 6));
+    RT_HIP(ctx, arena.alloc(&d4, (size_t)n * 2));
+    RT_HIP(ctx, arena.alloc(&dout, (size_t)n * 5));
     RT_HIP(ctx, hipMemcpyAsync(d3, origins, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
     RT_HIP(ctx, hipMemcpyAsync(d3 + (size_t)3 * n, directions, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
     int rc = rt_pack_rays_impl(ctx, d3, d3 + (size_t)3 * n, n, d4, d4 + n);
@@ -150,9 +151,6 @@ extern "C" int rt_trace_primitives(RtContext *ctx, const float *origins, const f
     if (out_primitive) RT_HIP(ctx, hipMemcpyAsync(out_primitive, dout + n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (out_normal) RT_HIP(ctx, hipMemcpyAsync(out_normal, dout + (size_t)2 * n, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(d3);
-    (void)hipFree(d4);
-    (void)hipFree(dout);
     rt_timer_resolve(ctx);
     return RT_OK;
 }

@@ -939,9 +939,10 @@ int rt_build_impl(RtContext *ctx)
     RtAABB *wBvhData = nullptr;
     BuildPlan *plan = nullptr;
     float4 *wLeafBox = nullptr;
+    RtArena arena(ctx->stream);             // scratch and events go when the build ends, however it ends
 
-    RT_HIP(ctx, dalloc(&plan, 1));
-    RT_HIP(ctx, dalloc(&wLeafBox, (size_t)N * 2));
+    RT_HIP(ctx, arena.alloc(&plan, 1));
+    RT_HIP(ctx, arena.alloc(&wLeafBox, (size_t)N * 2));
     RT_HIP(ctx, dalloc(&ctx->dTriAABB, (size_t)N));
     RT_HIP(ctx, dalloc(&ctx->dMortonUnsorted, (size_t)N));
     RT_HIP(ctx, dalloc(&ctx->dMortonSortedRaw, (size_t)N));
@@ -957,29 +958,29 @@ int rt_build_impl(RtContext *ctx)
     RT_HIP(ctx, dalloc(&ctx->dLeafTri, (size_t)N));
     RT_HIP(ctx, dalloc(&ctx->dLeafShade, (size_t)N));
     RT_HIP(ctx, dalloc(&ctx->dLeafRank, (size_t)N));
-    RT_HIP(ctx, dalloc(&sc.keysB, (size_t)N));
-    RT_HIP(ctx, dalloc(&sc.valsB, (size_t)N));
-    RT_HIP(ctx, dalloc(&sc.blockHist, (size_t)sc.histLen));
-    RT_HIP(ctx, dalloc(&sc.scanSums, (size_t)nbScanMax + 1));
-    RT_HIP(ctx, dalloc(&sc.done, (size_t)NI));
-    RT_HIP(ctx, dalloc(&sc.undone[0], (size_t)NI));
-    RT_HIP(ctx, dalloc(&sc.undone[1], (size_t)NI));
-    RT_HIP(ctx, dalloc(&sc.counts, (size_t)PASS_COUNT_WORDS));
-    RT_HIP(ctx, dalloc(&wKeys, (size_t)N));
-    RT_HIP(ctx, dalloc(&wCodes, (size_t)N));
-    RT_HIP(ctx, dalloc(&wSortedIdx, (size_t)N));
-    RT_HIP(ctx, dalloc(&wLeft, (size_t)NI));
-    RT_HIP(ctx, dalloc(&wRight, (size_t)NI));
-    RT_HIP(ctx, dalloc(&wParent, (size_t)NI));
-    RT_HIP(ctx, dalloc(&wLeafParent, (size_t)N));
-    RT_HIP(ctx, dalloc(&refSize, (size_t)NI));
-    RT_HIP(ctx, dalloc(&walkLeafOfTri, (size_t)N));
-    RT_HIP(ctx, dalloc(&wBvhData, (size_t)NI));
+    RT_HIP(ctx, arena.alloc(&sc.keysB, (size_t)N));
+    RT_HIP(ctx, arena.alloc(&sc.valsB, (size_t)N));
+    RT_HIP(ctx, arena.alloc(&sc.blockHist, (size_t)sc.histLen));
+    RT_HIP(ctx, arena.alloc(&sc.scanSums, (size_t)nbScanMax + 1));
+    RT_HIP(ctx, arena.alloc(&sc.done, (size_t)NI));
+    RT_HIP(ctx, arena.alloc(&sc.undone[0], (size_t)NI));
+    RT_HIP(ctx, arena.alloc(&sc.undone[1], (size_t)NI));
+    RT_HIP(ctx, arena.alloc(&sc.counts, (size_t)PASS_COUNT_WORDS));
+    RT_HIP(ctx, arena.alloc(&wKeys, (size_t)N));
+    RT_HIP(ctx, arena.alloc(&wCodes, (size_t)N));
+    RT_HIP(ctx, arena.alloc(&wSortedIdx, (size_t)N));
+    RT_HIP(ctx, arena.alloc(&wLeft, (size_t)NI));
+    RT_HIP(ctx, arena.alloc(&wRight, (size_t)NI));
+    RT_HIP(ctx, arena.alloc(&wParent, (size_t)NI));
+    RT_HIP(ctx, arena.alloc(&wLeafParent, (size_t)N));
+    RT_HIP(ctx, arena.alloc(&refSize, (size_t)NI));
+    RT_HIP(ctx, arena.alloc(&walkLeafOfTri, (size_t)N));
+    RT_HIP(ctx, arena.alloc(&wBvhData, (size_t)NI));
 
     hipStream_t st = ctx->stream;
-    hipEvent_t e0, e1;
-    RT_HIP(ctx, hipEventCreate(&e0));
-    RT_HIP(ctx, hipEventCreate(&e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    RT_HIP(ctx, arena.event(&e0));
+    RT_HIP(ctx, arena.event(&e1));
     RT_HIP(ctx, hipEventRecord(e0, st));
     RT_HIP(ctx, hipMemsetAsync(sc.counts, 0, PASS_COUNT_WORDS * sizeof(uint32_t), st));
 
@@ -1050,11 +1051,6 @@ int rt_build_impl(RtContext *ctx)
     float ms = 0;
     RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
     ctx->buildMs = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    void *scratch[] = {sc.keysB, sc.valsB, sc.blockHist, sc.scanSums, sc.done, sc.undone[0], sc.undone[1], sc.counts, wKeys, wCodes, wSortedIdx, wLeft, wRight, wParent,
-                       wLeafParent, refSize, walkLeafOfTri, wBvhData, plan, wLeafBox};
-    for (void *q : scratch) (void)hipFree(q);
     ctx->built = true;
     return RT_OK;
 }

@@ -1383,7 +1383,8 @@ int rt_trace_device_static_impl(RtContext *ctx, const float4 *o, const float4 *d
 int rt_trace_primitives_impl(RtContext *ctx, const float4 *o, const float4 *d, uint32_t n, float *t, uint32_t *prim, float *normal3)
 {
     RtHitRec *hits = nullptr;
-    RT_HIP(ctx, hipMalloc((void **)&hits, (size_t)n * sizeof(RtHitRec)));
+    RtArena arena(ctx->stream);
+    RT_HIP(ctx, arena.alloc(&hits, (size_t)n));
     ArraySrc src;
     src.org = o;
     src.dir = d;
@@ -1395,7 +1396,6 @@ int rt_trace_primitives_impl(RtContext *ctx, const float4 *o, const float4 *d, u
     hipLaunchKernelGGL(k_brute_unpack, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->brute, o, d, hits, n, t, prim, normal3);
     RT_HIP(ctx, hipGetLastError());
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(hits);
     return RT_OK;
 }
 

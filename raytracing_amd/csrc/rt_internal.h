@@ -275,6 +275,36 @@ void rt_free_build(RtContext *ctx);
 // render.hip
 RtSceneView rt_scene_view(RtContext *ctx);
 int rt_alloc_render(RtContext *ctx);
+// What a call borrows and gives back when it ends, however it ends (every error path returns early): scratch
+// buffers and events.  The stream is drained first, because launches in flight may still use the buffers.
+struct RtArena {
+    hipStream_t stream;
+    std::vector<void *> buffers;
+    std::vector<hipEvent_t> events;
+    explicit RtArena(hipStream_t s) : stream(s) {}
+    RtArena(const RtArena &) = delete;
+    RtArena &operator=(const RtArena &) = delete;
+    template <typename T>
+    hipError_t alloc(T **p, size_t count)
+    {
+        const hipError_t e = hipMalloc((void **)p, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) buffers.push_back(*p);
+        return e;
+    }
+    hipError_t event(hipEvent_t *e)
+    {
+        const hipError_t rc = hipEventCreate(e);
+        if (rc == hipSuccess) events.push_back(*e);
+        return rc;
+    }
+    ~RtArena()
+    {
+        if (!buffers.empty()) (void)hipStreamSynchronize(stream);
+        for (void *q : buffers) (void)hipFree(q);
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    }
+};
+
 enum { RT_EAGER_NONE = 0, RT_EAGER_SETUP = 1, RT_EAGER_FORKED = 2 };   // nothing / pass prepared / its rays already being walked
 int rt_eager_cancel(RtContext *ctx);
 uint32_t rt_batch_frames_rule(uint32_t nSlots, uint32_t option, uint32_t wanted);
