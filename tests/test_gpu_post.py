@@ -49,6 +49,28 @@ def test_color_grading_bit_exact(core, oracle, name):
     assert_frames_equal(core.readback(wire.IMAGE_POSTPROCESS), oracle.post_color_grading(img, lut), f"colour grading through {name}")
 
 
+def test_published_gradings_agree_through_the_kernel(core):
+    """rt_post_color_grading against the reference's own outputs: the five published images of one frame graded
+    through five tables (README.md "Color grading") have their ungraded frame in common, so the colours the kernel
+    maps onto one image, sent through another table, must give that table's image (tests/test_post_cpu.py,
+    check_cross_table: median <= 2 and 90th percentile <= 6 of 255 counts; the wrong table is > 6 off at the median)."""
+    from tests.test_post_cpu import check_cross_table
+    tables = luts()
+
+    def grade(lin, name):
+        n, w = len(lin), 1024
+        h = (n + w - 1) // w
+        img = np.zeros((h * w, 4), np.float32)
+        img[:n, :3] = lin
+        img[:, 3] = 1.0
+        core.image_upload(img.reshape(h, w, 4))
+        core.post_lut_upload(tables[name])
+        core.post_color_grading(wire.IMAGE_USER)
+        return core.readback(wire.IMAGE_POSTPROCESS).reshape(-1, 4)[:n, :3].astype(np.float64)
+
+    check_cross_table(grade)
+
+
 BLOOM_CASES = [
     dict(),                                                                      # the reference's defaults
     dict(wrapMode=wire.WRAP_REPEAT),

@@ -3,7 +3,9 @@ mirror of PostProcessStack.  The reference has no test or golden output for this
 (parity unpinned); the anchors here are (1) the reference's own look-up tables
 (tests/golden/reference_luts.npz, made by make_post_golden.py): grading through its
 NeutralLUT_32 must be the identity up to the table's resolution; (2) an independent numpy
-statement of every stage in float64."""
+statement of every stage in float64; (3) the five published gradings of one frame
+(tests/golden/reference_graded_pixels.npz), which must agree with each other through the
+grading operator."""
 import os
 
 import numpy as np
@@ -26,6 +28,65 @@ def hdr_image(w, h, seed=3, peak=4.0):
 def luts():
     z = np.load(os.path.join(GOLDEN, "reference_luts.npz"))
     return {k: png.texture_from_u8(z[k]) for k in z.files}
+
+
+def graded_pixels():
+    """The same 20 000 pixels of the five published gradings of one frame (tests/golden/make_post_golden.py)."""
+    z = np.load(os.path.join(GOLDEN, "reference_graded_pixels.npz"))
+    return {k: z[k] for k in z.files if k not in ("positions", "rows_skipped")}
+
+
+def srgb_to_linear(c):
+    c = np.asarray(c, np.float64)
+    return np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+
+
+def linear_to_srgb(c):
+    c = np.clip(np.asarray(c, np.float64), 0.0, 1.0)
+    return np.where(c <= 0.0031308, c * 12.92, 1.055 * c ** (1 / 2.4) - 0.055)
+
+
+def cross_table_errors(grade, source="Urban_cowboy", grid=80):
+    """The published gradings have their ungraded frame in common.  `grade(linear_rgb[n, 3], table) -> linear_rgb`
+    is the operator under test: the colours it maps onto the `source` image are found (densest-grid nearest
+    neighbour in display space), pushed through every other table, and compared with that table's published
+    image.  Returns {table: (median, 90th percentile) of the absolute error in 8-bit counts}."""
+    from scipy.spatial import cKDTree
+    px = graded_pixels()
+    g = (np.arange(grid) + 0.5) / grid
+    cand = srgb_to_linear(np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3))
+    shown = linear_to_srgb(grade(cand, source))
+    _, idx = cKDTree(shown).query(px[source].astype(np.float64) / 255.0)
+    frame = cand[idx]                                          # the ungraded frame at the sampled pixels, as estimated
+    out = {}
+    for name, want in px.items():
+        err = np.abs(linear_to_srgb(grade(frame, name)) * 255.0 - want.astype(np.float64))
+        out[name] = (float(np.median(err)), float(np.percentile(err, 90)))
+    return out, frame
+
+
+def check_cross_table(grade):
+    errs, frame = cross_table_errors(grade)
+    for name, (med, p90) in errs.items():
+        assert med <= 2.0 and p90 <= 6.0, (name, med, p90)     # measured: median 0.6 - 1.2, 90th percentile 1.5 - 3.5 counts
+    # the pairing matters: the wrong table for an image is far off
+    px = graded_pixels()
+    wrong = np.abs(linear_to_srgb(grade(frame, "Bleach_Bypass")) * 255.0 - px["Candlelight"].astype(np.float64))
+    assert np.median(wrong) > 6.0, float(np.median(wrong))
+
+
+def test_published_gradings_agree_through_the_checker():
+    """oracle/rt_post_oracle.cpp against the reference's own outputs: five published images of one frame, each
+    through another table (README.md "Color grading")."""
+    tables = luts()
+
+    def grade(lin, name):
+        img = np.zeros((1, len(lin), 4), np.float32)
+        img[0, :, :3] = lin
+        img[..., 3] = 1.0
+        return oracle_py.post_color_grading(img, tables[name])[0, :, :3].astype(np.float64)
+
+    check_cross_table(grade)
 
 
 # ---------------------------------------------------------------- independent numpy statements
