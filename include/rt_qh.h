@@ -177,8 +177,9 @@ RT_HD bool rt_slab_finite(const RtRaySlab &s)
 #define RT_QH_LO(w) rt_qh_value((w) & 0xFFFFu)
 #define RT_QH_HI(w) rt_qh_value((w) >> 16)
 
-/* false ONLY when the reference's test certainly fails for the grid box (wx, wy, wz) */
-RT_HD bool rt_slab_maybe(const RtRaySlab &s, uint32_t wx, uint32_t wy, uint32_t wz)
+/* false ONLY when the reference's test certainly fails for the grid box (wx, wy, wz); *tnear: where the ray
+ * enters the box at the earliest (a lower bound, for ordering only) */
+RT_HD bool rt_slab_maybe_near(const RtRaySlab &s, uint32_t wx, uint32_t wy, uint32_t wz, float *tnear)
 {
     const float t1x = __builtin_fmaf(RT_QH_LO(wx), s.A[0], s.Blo[0]);
     const float t1y = __builtin_fmaf(RT_QH_LO(wy), s.A[1], s.Blo[1]);
@@ -189,14 +190,21 @@ RT_HD bool rt_slab_maybe(const RtRaySlab &s, uint32_t wx, uint32_t wy, uint32_t 
     const float tn = __builtin_fmaxf(__builtin_fminf(t1x, t2x), __builtin_fmaxf(__builtin_fminf(t1y, t2y), __builtin_fminf(t1z, t2z)));
     const float tf = __builtin_fminf(__builtin_fmaxf(t1x, t2x), __builtin_fminf(__builtin_fmaxf(t1y, t2y), __builtin_fmaxf(t1z, t2z)));
     const bool sureMiss = tn > tf || tf < 0.0f;
+    *tnear = tn;
     return !sureMiss;
+}
+
+RT_HD bool rt_slab_maybe(const RtRaySlab &s, uint32_t wx, uint32_t wy, uint32_t wz)
+{
+    float tn;
+    return rt_slab_maybe_near(s, wx, wy, wz, &tn);
 }
 
 #ifdef __cplusplus
 /* The same boolean for a ray (rt_slab_finite) whose octant is OCT: near and far planes are picked
  * by the sign of A, no min / max per axis. */
 template <uint32_t OCT>
-RT_HD bool rt_slab_maybe_octant(const RtRaySlab &s, uint32_t wx, uint32_t wy, uint32_t wz)
+RT_HD bool rt_slab_maybe_octant_near(const RtRaySlab &s, uint32_t wx, uint32_t wy, uint32_t wz, float *tnear)
 {
     const float nx = (OCT & 1u) ? __builtin_fmaf(RT_QH_HI(wx), s.A[0], s.Bhi[0]) : __builtin_fmaf(RT_QH_LO(wx), s.A[0], s.Blo[0]);
     const float fx = (OCT & 1u) ? __builtin_fmaf(RT_QH_LO(wx), s.A[0], s.Blo[0]) : __builtin_fmaf(RT_QH_HI(wx), s.A[0], s.Bhi[0]);
@@ -207,7 +215,15 @@ RT_HD bool rt_slab_maybe_octant(const RtRaySlab &s, uint32_t wx, uint32_t wy, ui
     const float tn = __builtin_fmaxf(nx, __builtin_fmaxf(ny, nz));
     const float tf = __builtin_fminf(fx, __builtin_fminf(fy, fz));
     const bool sureMiss = tn > tf || tf < 0.0f;
+    *tnear = tn;
     return !sureMiss;
+}
+
+template <uint32_t OCT>
+RT_HD bool rt_slab_maybe_octant(const RtRaySlab &s, uint32_t wx, uint32_t wy, uint32_t wz)
+{
+    float tn;
+    return rt_slab_maybe_octant_near<OCT>(s, wx, wy, wz, &tn);
 }
 #endif
 

@@ -299,7 +299,10 @@ struct WalkState {
 // room for two more entries waits; the phase ends when too few lanes are still walking (the others wait for
 // triangle tests, a refill or retirement).  OCT < 8: every ray of the wave that is in the tree runs the same way
 // along each axis (rt_slab_octant) and the box test picks near and far planes without min / max; OCT == 8: any mix.
-template <uint32_t OCT, bool COUNT>
+// NEAR: where both children have to be visited the walk goes on with the one the ray enters first (no result depends
+// on the order: every passing node is visited, equal distances are settled by leafRank).  For rays that may stop at
+// their first hit (Src::FIRST_HIT_MAY_DECIDE) the hit then comes sooner.
+template <uint32_t OCT, bool COUNT, bool NEAR>
 __device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySlab &slab, WalkState &w, uint32_t *stk, uint32_t *pend,
                                            uint32_t *spill, const uint32_t spillLanes, uint32_t cnt[3], const bool feedExhausted)
 {
@@ -316,8 +319,9 @@ __device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySla
             // keep the fetch at two 16-byte loads per lane (the compiler would otherwise split the second)
             asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));
             const uint32_t l = qb.z, rr = qb.w;
-            const bool hitL = OCT < 8u ? rt_slab_maybe_octant<(OCT & 7u)>(slab, qa.x, qa.y, qa.z) : rt_slab_maybe(slab, qa.x, qa.y, qa.z);
-            const bool hitR = OCT < 8u ? rt_slab_maybe_octant<(OCT & 7u)>(slab, qa.w, qb.x, qb.y) : rt_slab_maybe(slab, qa.w, qb.x, qb.y);
+            float nearL, nearR;
+            const bool hitL = OCT < 8u ? rt_slab_maybe_octant_near<(OCT & 7u)>(slab, qa.x, qa.y, qa.z, &nearL) : rt_slab_maybe_near(slab, qa.x, qa.y, qa.z, &nearL);
+            const bool hitR = OCT < 8u ? rt_slab_maybe_octant_near<(OCT & 7u)>(slab, qa.w, qb.x, qb.y, &nearR) : rt_slab_maybe_near(slab, qa.w, qb.x, qb.y, &nearR);
             const bool lLeaf = (l & RT_LEAF_BIT) != 0, rLeaf = (rr & RT_LEAF_BIT) != 0;
             if (COUNT) cnt[0] += 2u;
             // Straight-line bookkeeping: every store below happens whether or not it is needed
@@ -327,27 +331,32 @@ __device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySla
             pend[w.npend * TRV_THREADS] = rr & ~RT_LEAF_BIT;
             w.npend += (rLeaf && hitR) ? 1u : 0u;
             const bool goL = !lLeaf && hitL, goR = !rLeaf && hitR;
+            // with both to visit: `first` now, `later` from the stack (the right one first unless NEAR says otherwise)
+            const bool leftFirst = NEAR && nearL < nearR;
+            const uint32_t first = leftFirst ? l : rr, later = leftFirst ? rr : l;
             if (__builtin_expect(w.sp < TRV_STACK_LDS, 1)) {
                 // `tos` mirrors level sp-1 in a register, so a pop needs no LDS round trip before
                 // the next node can be fetched; the level below is read now and taken over at the
                 // start of this lane's next step (level 0 holds TRV_DONE).
-                stk[w.sp * TRV_THREADS] = l;                         // right first, left later
+                stk[w.sp * TRV_THREADS] = later;
                 w.below = stk[(w.sp > 1u ? w.sp - 2u : 0u) * TRV_THREADS];
                 const bool both = goL && goR, none = !(goL || goR);
                 uint32_t next = goR ? rr : l;
+                next = both ? first : next;
                 next = none ? w.tos : next;
                 w.node = next;
-                w.tos = both ? l : w.tos;
+                w.tos = both ? later : w.tos;
                 w.popped = none;
                 w.sp += both ? 1u : 0u;
                 w.sp -= none ? 1u : 0u;
             } else {                                                 // deep levels live in HBM
                 w.node = goR ? rr : l;
                 if (goL && goR) {
+                    w.node = first;
                     if (w.sp < RT_STACK_DEPTH) {
-                        spill[(size_t)(w.sp - TRV_STACK_LDS) * spillLanes] = l;
+                        spill[(size_t)(w.sp - TRV_STACK_LDS) * spillLanes] = later;
                         w.sp++;
-                        w.tos = l;
+                        w.tos = later;
                     } else {
                         // Deeper than the stack (rotations may lengthen a path of the tree past the 32 levels a Karras
                         // tree has): the ray starts over on the reference's tree with the walk that needs no stack
@@ -449,15 +458,15 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
             const bool uniform = (sx == 0ull || sx == in) && (sy == 0ull || sy == in) && (sz == 0ull || sz == in);
             const uint32_t oct = uniform ? ((sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u)) : 8u;
             switch (oct) {
-            case 0: node_phase<0, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
-            case 1: node_phase<1, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
-            case 2: node_phase<2, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
-            case 3: node_phase<3, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
-            case 4: node_phase<4, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
-            case 5: node_phase<5, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
-            case 6: node_phase<6, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
-            case 7: node_phase<7, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
-            default: node_phase<8, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
+            case 0: node_phase<0, COUNT, Src::FIRST_HIT_MAY_DECIDE>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
+            case 1: node_phase<1, COUNT, Src::FIRST_HIT_MAY_DECIDE>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
+            case 2: node_phase<2, COUNT, Src::FIRST_HIT_MAY_DECIDE>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
+            case 3: node_phase<3, COUNT, Src::FIRST_HIT_MAY_DECIDE>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
+            case 4: node_phase<4, COUNT, Src::FIRST_HIT_MAY_DECIDE>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
+            case 5: node_phase<5, COUNT, Src::FIRST_HIT_MAY_DECIDE>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
+            case 6: node_phase<6, COUNT, Src::FIRST_HIT_MAY_DECIDE>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
+            case 7: node_phase<7, COUNT, Src::FIRST_HIT_MAY_DECIDE>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
+            default: node_phase<8, COUNT, Src::FIRST_HIT_MAY_DECIDE>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
             }
         }
 
