@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Phase profile of the one-ray-per-lane walker.  Needs a library built with -DTRV_PROFILE:
    hipcc ... -DTRV_PROFILE -shared -o build_ab/lib_prof.so api.hip build.hip render.hip
-Usage: walker_profile.py build_ab/lib_prof.so [frames]"""
+Usage: walker_profile.py build_ab/lib_prof.so [frames] [ranks: profile rank 0's share of the frame]"""
 import ctypes as C
 import json
 import os
@@ -14,7 +14,11 @@ from raytracing_amd import native, scenes  # noqa: E402
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 sc = scenes.car_standin(1920, 1080)
 core = native.RtCore(0)
-core.upload(sc); core.bvh_build(); core.set_params(sc.params)
+core.upload(sc); core.bvh_build()
+params = sc.params.copy()
+if len(sys.argv) > 3:
+    params.tileRank, params.tileCount, params.tileSize = 0, int(sys.argv[3]), 64
+core.set_params(params)
 seeds = scenes.frame_seeds(frames, 1)
 core.render_frames(seeds)
 core.reset_stats()
