@@ -427,7 +427,8 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *                          images bit for bit; 6.4 instead of 9.8 ms per 1080p frame of the car scene.  Any call
  *                          that changes the scene, the parameters or an option in between drops the prepared pass, and
  *                          rt_dispatch_shadowmap traces its own primary rays as it does with the option off or while
- *                          counters are enabled (the work counters keep the two kernels apart).
+ *                          counters are enabled (the work counters keep the two kernels apart).  Between the two calls
+ *                          RT_IMAGE_SHADOWMAP is half written: read it after rt_dispatch_shadowmap, as the reference does.
  *   RT_OPT_OVERLAP_AFTER   0..6, default 0: the bounce whose extend launch the overlap starts after (0: as soon as the
  *                          primary hits are known)
  *   RT_OPT_OVERLAP_CUS     compute units the bounce launches keep meanwhile, default 64 (multiples of 32 measured best);
