@@ -196,6 +196,10 @@ __device__ __forceinline__ void flush_counters(const RtSceneView &sv, uint32_t r
 #ifndef TRV_CHUNK_SHARE
 #define TRV_CHUNK_SHARE 4u      // a reservation is at most 1/SHARE of an even share of the rays that are left (2 / 4 / 8 / 32: 110.5 / 110.7 / 113.0 / 133.9 ms per image)
 #endif
+// The feed's state is the same in every lane of a wave, and says so to the compiler (which then keeps it in scalar
+// registers).
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+
 struct RayFeed {
     uint32_t *cursor;
     uint32_t total, next, end, chunk, waves2;    // wave-uniform
@@ -211,12 +215,12 @@ struct RayFeed {
     __device__ __forceinline__ void init(uint32_t *c, uint32_t n)
     {
         cursor = c;
-        total = n;
+        total = wave_uniform(n);
         next = end = 0;
         waves2 = gridDim.x * (blockDim.x >> 6) * TRV_CHUNK_SHARE;
-        chunk = chunk_for(n);
+        chunk = chunk_for(total);
         lastChunk = false;
-        exhausted = n == 0;
+        exhausted = total == 0;
     }
     // Wave-uniform call: hands up to `want` rays to the lanes with rank 0..want-1 (`rank` = this
     // lane's position among the asking lanes).  Returns this lane's ray or TRV_DONE.
@@ -226,7 +230,7 @@ struct RayFeed {
             const uint32_t take = chunk ? chunk : want;
             uint32_t base = 0;
             if ((threadIdx.x & 63u) == 0) base = atomicAdd(cursor, take);
-            base = __shfl(base, 0, 64);
+            base = wave_uniform(base);                         // lane 0's
             next = base < total ? base : total;
             end = total - next < take ? total : next + take;
             lastChunk = end == total;
@@ -349,6 +353,13 @@ __device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySla
                 w.popped = none;
                 w.sp += both ? 1u : 0u;
                 w.sp -= none ? 1u : 0u;
+            } else if (__builtin_expect(w.sp > RT_STACK_DEPTH, 0)) {
+                // No walk gets here.  A stack pointer out of range would index the spill area anywhere, so whatever
+                // produced it, the ray starts over with the walk that has no stack.
+                w.node = TRV_DONE;
+                w.sp = 1;
+                w.tos = TRV_REDO;
+                w.npend = 0;
             } else {                                                 // deep levels live in HBM
                 w.node = goR ? rr : l;
                 if (goL && goR) {
