@@ -429,6 +429,15 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *                          rt_dispatch_shadowmap traces its own primary rays as it does with the option off or while
  *                          counters are enabled (the work counters keep the two kernels apart).  Between the two calls
  *                          RT_IMAGE_SHADOWMAP is half written: read it after rt_dispatch_shadowmap, as the reference does.
+ *   RT_OPT_PRUNE_BY_DISTANCE 1 (default): a ray does not enter a box that begins more than 1/64 beyond the closest hit it
+ *                          holds.  The reference enters every box the ray passes (BVHRayTracing.cginc:87-123 has no
+ *                          distance test) and keeps the closest hit; a triangle in a box left out lies behind the hit
+ *                          already held, so the hit returned is the same -- up to this: a hit's distance and a box's
+ *                          entry distance are separate float computations, and for a ray within about 1e-5 rad of a
+ *                          large triangle's plane Moller-Trumbore's distance can be off by more than the 1/64 of room.
+ *                          No such ray turned up in any test (the full-size frames are bit-identical on and off);
+ *                          0 = the reference's walk, box for box.  Work counters (rt_enable_counters) always count
+ *                          that walk.
  *   RT_OPT_OVERLAP_AFTER   0..6, default 0: the bounce whose extend launch the overlap starts after (0: as soon as the
  *                          primary hits are known)
  *   RT_OPT_OVERLAP_CUS     compute units the bounce launches keep meanwhile, default 64 (multiples of 32 measured best);
@@ -446,6 +455,7 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
 #define RT_OPT_FIRST_HIT_SHADOW 9
 #define RT_OPT_CASTER_BOX 10
 #define RT_OPT_EAGER_SHADOWMAP 11
+#define RT_OPT_PRUNE_BY_DISTANCE 12
 int rt_set_option(RtContext *ctx, int option, int value);
 
 /* ------------------------------------------------------------------- stats */

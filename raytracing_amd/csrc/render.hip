@@ -698,6 +698,7 @@ RtSceneView rt_scene_view(RtContext *ctx)
     // walker launches that may be on the chip together spill into different areas
     sv.stackSpill = ctx->dStackSpill + (size_t)ctx->spillArea * ctx->numCU * RT_SPILL_WORDS_PER_CU;
     sv.errorFlag = ctx->dErrorFlag;
+    sv.pruneScale = ctx->optPruneByDistance ? RT_PRUNE_SCALE : rt_inf();
     return sv;
 }
 

@@ -83,6 +83,7 @@ struct RtSceneView {
     const float4 *cube;
     uint32_t cubeSize;
     uint32_t *stackSpill;      // deep stack levels of the one-ray-per-lane walker
+    float pruneScale;          // a box whose entry distance exceeds (closest hit so far) x this is not entered; +inf: none is left out
     unsigned long long *stats; // 8 counters or nullptr
     uint32_t *errorFlag;
 };
@@ -214,6 +215,7 @@ struct RtContext {
     bool optCasterBox = true;             // shadow rays that cannot meet a shadow caster are not walked
     bool optFirstHitShadow = true;        // shadow rays that cannot meet a non-casting triangle stop at their first hit
     bool optOverlapShadow = true;         // walk the shadow rays while the later bounces run (render.hip, overlap_fork)
+    bool optPruneByDistance = true;       // boxes beyond the closest hit found so far are not entered (RT_OPT_PRUNE_BY_DISTANCE)
     bool optEagerShadowMap = true;        // rt_dispatch starts the ShadowMap pass of its frame (render.hip, rt_dispatch_impl)
     int eagerShadow = 0;                  // RT_EAGER_*: what rt_dispatch left for rt_dispatch_shadowmap
     uint32_t optOverlapAfter = 0;         // ... from the extend launch of this bounce on

@@ -60,6 +60,10 @@
 #define TRV_WALK_NUM 3u         // leave the node phase when fewer than NUM/DEN of the lanes that still
 #define TRV_WALK_DEN 4u         // have nodes to visit can go on (the rest wait for triangle tests)
 #endif
+// Boxes that begin beyond the closest hit a ray holds are not entered (RT_OPT_PRUNE_BY_DISTANCE): "beyond" with this
+// much room, because the distance of a hit (Moller-Trumbore) and the entry distance of a box (slab test) are two
+// different float computations and only agree to rounding.
+#define RT_PRUNE_SCALE 1.015625f
 #define TRV_DONE 0xFFFFFFFFu
 #define TRV_REDO 0xFFFFFFFEu    // in WalkState::tos of a lane whose node is TRV_DONE: this ray takes the exact, stackless walk next
 #define TRV_LDS_WORDS ((TRV_STACK_LDS + TRV_PEND_CAP) * TRV_THREADS)
@@ -304,11 +308,18 @@ struct WalkState {
 // triangle tests, a refill or retirement).  OCT < 8: every ray of the wave that is in the tree runs the same way
 // along each axis (rt_slab_octant) and the box test picks near and far planes without min / max; OCT == 8: any mix.
 // NEAR: where both children have to be visited the walk goes on with the one the ray enters first (no result depends
-// on the order: every passing node is visited, equal distances are settled by leafRank).  For rays that may stop at
-// their first hit (Src::FIRST_HIT_MAY_DECIDE) the hit then comes sooner.
+// on the order: equal distances are settled by leafRank).  For rays that may stop at their first hit
+// (Src::FIRST_HIT_MAY_DECIDE) the hit then comes sooner, and for the others the closest hit, which `limit` then uses:
+// limit: this lane's ray does not enter a box whose entry distance (a lower bound: the slab interval the walker sees
+// contains the reference's) exceeds it.  The caller passes (distance of the closest hit so far) x RT_PRUNE_SCALE, or
+// +inf.  A triangle in a box left out lies, to rounding, behind the hit the ray already holds and could not replace
+// it; "to rounding" is where this differs from the reference's walk, which enters every box the ray passes: the two
+// return different hits only if Moller-Trumbore puts a triangle more than 1.5 % nearer than the box that holds it,
+// which takes a ray within 1e-5 rad of the triangle's plane.
 template <uint32_t OCT, bool COUNT, bool NEAR>
 __device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySlab &slab, WalkState &w, uint32_t *stk, uint32_t *pend,
-                                           uint32_t *spill, const uint32_t spillLanes, uint32_t cnt[3], const bool feedExhausted)
+                                           uint32_t *spill, const uint32_t spillLanes, uint32_t cnt[3], const bool feedExhausted,
+                                           const float limit)
 {
     for (;;) {
         const bool act = w.node != TRV_DONE && w.npend <= TRV_PEND_CAP - 2;
@@ -324,8 +335,9 @@ __device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySla
             asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));
             const uint32_t l = qb.z, rr = qb.w;
             float nearL, nearR;
-            const bool hitL = OCT < 8u ? rt_slab_maybe_octant_near<(OCT & 7u)>(slab, qa.x, qa.y, qa.z, &nearL) : rt_slab_maybe_near(slab, qa.x, qa.y, qa.z, &nearL);
-            const bool hitR = OCT < 8u ? rt_slab_maybe_octant_near<(OCT & 7u)>(slab, qa.w, qb.x, qb.y, &nearR) : rt_slab_maybe_near(slab, qa.w, qb.x, qb.y, &nearR);
+            const bool maybeL = OCT < 8u ? rt_slab_maybe_octant_near<(OCT & 7u)>(slab, qa.x, qa.y, qa.z, &nearL) : rt_slab_maybe_near(slab, qa.x, qa.y, qa.z, &nearL);
+            const bool maybeR = OCT < 8u ? rt_slab_maybe_octant_near<(OCT & 7u)>(slab, qa.w, qb.x, qb.y, &nearR) : rt_slab_maybe_near(slab, qa.w, qb.x, qb.y, &nearR);
+            const bool hitL = COUNT ? maybeL : (maybeL && nearL <= limit), hitR = COUNT ? maybeR : (maybeR && nearR <= limit);
             const bool lLeaf = (l & RT_LEAF_BIT) != 0, rLeaf = (rr & RT_LEAF_BIT) != 0;
             if (COUNT) cnt[0] += 2u;
             // Straight-line bookkeeping: every store below happens whether or not it is needed
@@ -468,16 +480,19 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
             const unsigned long long sx = __ballot(slab.A[0] < 0.0f) & in, sy = __ballot(slab.A[1] < 0.0f) & in, sz = __ballot(slab.A[2] < 0.0f) & in;
             const bool uniform = (sx == 0ull || sx == in) && (sy == 0ull || sy == in) && (sz == 0ull || sz == in);
             const uint32_t oct = uniform ? ((sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u)) : 8u;
+            // the counting walk enters every box the ray passes, as the checker's does (its counters are compared)
+            constexpr bool NEAR = Src::FIRST_HIT_MAY_DECIDE || !COUNT;
+            const float limit = COUNT ? rt_inf() : h.t * sv.pruneScale;
             switch (oct) {
-            case 0: node_phase<0, COUNT, Src::FIRST_HIT_MAY_DECIDE>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
-            case 1: node_phase<1, COUNT, Src::FIRST_HIT_MAY_DECIDE>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
-            case 2: node_phase<2, COUNT, Src::FIRST_HIT_MAY_DECIDE>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
-            case 3: node_phase<3, COUNT, Src::FIRST_HIT_MAY_DECIDE>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
-            case 4: node_phase<4, COUNT, Src::FIRST_HIT_MAY_DECIDE>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
-            case 5: node_phase<5, COUNT, Src::FIRST_HIT_MAY_DECIDE>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
-            case 6: node_phase<6, COUNT, Src::FIRST_HIT_MAY_DECIDE>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
-            case 7: node_phase<7, COUNT, Src::FIRST_HIT_MAY_DECIDE>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
-            default: node_phase<8, COUNT, Src::FIRST_HIT_MAY_DECIDE>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted); break;
+            case 0: node_phase<0, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;
+            case 1: node_phase<1, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;
+            case 2: node_phase<2, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;
+            case 3: node_phase<3, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;
+            case 4: node_phase<4, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;
+            case 5: node_phase<5, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;
+            case 6: node_phase<6, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;
+            case 7: node_phase<7, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;
+            default: node_phase<8, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;
             }
         }
 

@@ -90,7 +90,7 @@ class RtStats(C.Structure):
 # rt_set_option
 OPT_PACKET_SHADOW, OPT_PACKET_PRIMARY, OPT_PACKET_TRACE, OPT_BATCH_FRAMES, OPT_MATERIAL_SORT, OPT_TWO_STREAMS = 0, 1, 2, 3, 4, 5
 OPT_OVERLAP_SHADOW, OPT_OVERLAP_AFTER, OPT_OVERLAP_CUS = 6, 7, 8
-OPT_FIRST_HIT_SHADOW, OPT_CASTER_BOX, OPT_EAGER_SHADOWMAP = 9, 10, 11
+OPT_FIRST_HIT_SHADOW, OPT_CASTER_BOX, OPT_EAGER_SHADOWMAP, OPT_PRUNE_BY_DISTANCE = 9, 10, 11, 12
 
 
 class RtBloomParams(C.Structure):

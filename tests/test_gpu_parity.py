@@ -97,10 +97,14 @@ def test_first_hit_bit_exact(core, oracle, name, packets):
     got = core.trace_rays(o, d)
     st = core.stats()
     core.enable_counters(False)
-    got_plain = core.trace_rays(o, d)             # the build without counters is a different kernel
+    got_plain = core.trace_rays(o, d)             # the build without counters is a different kernel, and leaves out
+    core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 0)  # boxes beyond the closest hit unless told to enter them all
+    got_every_box = core.trace_rays(o, d)
+    core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 1)
     core.set_option(wire.OPT_PACKET_TRACE, False)
     for k in ("triangle", "t", "u", "v"):
         H.assert_bits_equal(got_plain[k], got[k], f"{k}: counting vs plain kernel")
+        H.assert_bits_equal(got_every_box[k], got[k], f"{k}: counting vs plain kernel entering every box")
     want = orc.trace(o, d)                        # the reference's walk
     # work counters: the packet walker takes the reference's walk node for node; the one-ray-per-lane
     # walker tests 16-bit outward-rounded boxes, restated on the CPU by trace(grid=True)

@@ -287,8 +287,9 @@ def test_config4_car_4k_eight_tile_sets_make_the_whole_frame(core):
 
 def test_car_1080p_execution_options_do_not_change_a_bit(core):
     """The bench workload at full size, 16 frames in flight: shadow rays that end at their first hit, the ShadowMap
-    pass walked while the later bounces run on masked streams, material-sorted shading and the frame-interleaved ray
-    queue against the plain settings (closest-hit shadow rays, one launch after the other, two batches of 8)."""
+    pass walked while the later bounces run on masked streams, material-sorted shading, boxes beyond the closest hit
+    left out and the frame-interleaved ray queue against the plain settings (closest-hit shadow rays, the reference's
+    walk box for box, one launch after the other, two batches of 8)."""
     sc = scenes.car_standin(1920, 1080)
     seeds = scenes.frame_seeds(16, seed=3)
     core.upload(sc)
@@ -300,6 +301,7 @@ def test_car_1080p_execution_options_do_not_change_a_bit(core):
         core.set_option(wire.OPT_CASTER_BOX, fast)
         core.set_option(wire.OPT_OVERLAP_SHADOW, fast)
         core.set_option(wire.OPT_MATERIAL_SORT, fast)
+        core.set_option(wire.OPT_PRUNE_BY_DISTANCE, fast)
         core.set_option(wire.OPT_BATCH_FRAMES, 0 if fast else 8)
         core.set_dirty()
         core.render_frames(seeds)
