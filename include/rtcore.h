@@ -436,8 +436,8 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *                          entry distance are separate float computations, and for a ray within about 1e-5 rad of a
  *                          large triangle's plane Moller-Trumbore's distance can be off by more than the 1/64 of room.
  *                          No such ray turned up in any test (the full-size frames are bit-identical on and off);
- *                          0 = the reference's walk, box for box.  Work counters (rt_enable_counters) always count
- *                          that walk.
+ *                          0 = the reference's walk, box for box (the one whose work counters, rt_enable_counters,
+ *                          equal the CPU checker's).
  *   RT_OPT_OVERLAP_AFTER   0..6, default 0: the bounce whose extend launch the overlap starts after (0: as soon as the
  *                          primary hits are known)
  *   RT_OPT_OVERLAP_CUS     compute units the bounce launches keep meanwhile, default 64 (multiples of 32 measured best);

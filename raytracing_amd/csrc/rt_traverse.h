@@ -337,7 +337,7 @@ __device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySla
             float nearL, nearR;
             const bool maybeL = OCT < 8u ? rt_slab_maybe_octant_near<(OCT & 7u)>(slab, qa.x, qa.y, qa.z, &nearL) : rt_slab_maybe_near(slab, qa.x, qa.y, qa.z, &nearL);
             const bool maybeR = OCT < 8u ? rt_slab_maybe_octant_near<(OCT & 7u)>(slab, qa.w, qb.x, qb.y, &nearR) : rt_slab_maybe_near(slab, qa.w, qb.x, qb.y, &nearR);
-            const bool hitL = COUNT ? maybeL : (maybeL && nearL <= limit), hitR = COUNT ? maybeR : (maybeR && nearR <= limit);
+            const bool hitL = maybeL && nearL <= limit, hitR = maybeR && nearR <= limit;
             const bool lLeaf = (l & RT_LEAF_BIT) != 0, rLeaf = (rr & RT_LEAF_BIT) != 0;
             if (COUNT) cnt[0] += 2u;
             // Straight-line bookkeeping: every store below happens whether or not it is needed
@@ -480,9 +480,8 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
             const unsigned long long sx = __ballot(slab.A[0] < 0.0f) & in, sy = __ballot(slab.A[1] < 0.0f) & in, sz = __ballot(slab.A[2] < 0.0f) & in;
             const bool uniform = (sx == 0ull || sx == in) && (sy == 0ull || sy == in) && (sz == 0ull || sz == in);
             const uint32_t oct = uniform ? ((sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u)) : 8u;
-            // the counting walk enters every box the ray passes, as the checker's does (its counters are compared)
-            constexpr bool NEAR = Src::FIRST_HIT_MAY_DECIDE || !COUNT;
-            const float limit = COUNT ? rt_inf() : h.t * sv.pruneScale;
+            constexpr bool NEAR = true;                              // every kind of ray gains: a hit found sooner, or a closer one
+            const float limit = h.t * sv.pruneScale;                 // +inf without a hit, or with the option off
             switch (oct) {
             case 0: node_phase<0, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;
             case 1: node_phase<1, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;

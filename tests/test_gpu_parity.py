@@ -92,10 +92,15 @@ def test_first_hit_bit_exact(core, oracle, name, packets):
     o = np.concatenate([o1, o2, o3])
     d = np.concatenate([d1, d2, d3])
     core.set_option(wire.OPT_PACKET_TRACE, packets)
+    core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 0)  # the walk whose work the checker counts: every box the ray passes
     core.enable_counters(True)
     core.reset_stats()
     got = core.trace_rays(o, d)
     st = core.stats()
+    core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 1)
+    core.reset_stats()
+    got_counting_fewer = core.trace_rays(o, d)
+    st_fewer = core.stats()
     core.enable_counters(False)
     got_plain = core.trace_rays(o, d)             # the build without counters is a different kernel, and leaves out
     core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 0)  # boxes beyond the closest hit unless told to enter them all
@@ -105,6 +110,11 @@ def test_first_hit_bit_exact(core, oracle, name, packets):
     for k in ("triangle", "t", "u", "v"):
         H.assert_bits_equal(got_plain[k], got[k], f"{k}: counting vs plain kernel")
         H.assert_bits_equal(got_every_box[k], got[k], f"{k}: counting vs plain kernel entering every box")
+        H.assert_bits_equal(got_counting_fewer[k], got[k], f"{k}: counting kernel, boxes beyond the closest hit left out")
+    assert st_fewer["rays"] == st["rays"] and st_fewer["hits"] == st["hits"]
+    assert st_fewer["internalVisits"] <= st["internalVisits"] and st_fewer["triTests"] <= st["triTests"]
+    if not packets and name in ("cornell", "soup20k"):
+        assert st_fewer["internalVisits"] < st["internalVisits"]
     want = orc.trace(o, d)                        # the reference's walk
     # work counters: the packet walker takes the reference's walk node for node; the one-ray-per-lane
     # walker tests 16-bit outward-rounded boxes, restated on the CPU by trace(grid=True)
