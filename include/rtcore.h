@@ -163,7 +163,7 @@ typedef struct RtStats {
     uint64_t hits;            /* rays that ended with a hit (h) */
     uint64_t paths;           /* camera paths generated */
     double buildMs;           /* device time of the last rt_bvh_build */
-    double renderMs;          /* device time of the last dispatch / render_frames */
+    double renderMs;          /* device time of the last rt_render_frames, or of the walk of the last rt_trace_rays* call */
     /* the part of rays / internalVisits / leafVisits / triTests / hits due to the 16 soft-shadow
      * rays per pixel of the ShadowMap pass (Shadow.cginc:95-111) */
     uint64_t shadowRays, shadowInternalVisits, shadowLeafVisits, shadowTriTests, shadowHits;

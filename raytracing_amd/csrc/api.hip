@@ -562,15 +562,25 @@ int rt_trace_rays(RtContext *ctx, const float *origins, const float *directions,
     RT_HIP(ctx, arena.alloc(&dout, (size_t)n * 4));
     RT_HIP(ctx, hipMemcpyAsync(d3, origins, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
     RT_HIP(ctx, hipMemcpyAsync(d3 + (size_t)3 * n, directions, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;     // round the walk itself: RtStats.renderMs of this call
+    RT_HIP(ctx, arena.event(&e0));
+    RT_HIP(ctx, arena.event(&e1));
     int rc = rt_pack_rays_impl(ctx, d3, d3 + (size_t)3 * n, n, d4, d4 + n);
-    if (!rc) rc = rt_trace_device_impl(ctx, d4, d4 + n, n, dh);
-    if (!rc) rc = rt_hits_to_host_impl(ctx, dh, n, dout, (uint32_t *)(dout + n), dout + (size_t)2 * n, dout + (size_t)3 * n);
+    if (rc) return rc;
+    RT_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    rc = rt_trace_device_impl(ctx, d4, d4 + n, n, dh);
+    if (rc) return rc;
+    RT_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    rc = rt_hits_to_host_impl(ctx, dh, n, dout, (uint32_t *)(dout + n), dout + (size_t)2 * n, dout + (size_t)3 * n);
     if (rc) return rc;
     if (out_t) RT_HIP(ctx, hipMemcpyAsync(out_t, dout, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (out_triangle) RT_HIP(ctx, hipMemcpyAsync(out_triangle, dout + n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (out_u) RT_HIP(ctx, hipMemcpyAsync(out_u, dout + (size_t)2 * n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (out_v) RT_HIP(ctx, hipMemcpyAsync(out_v, dout + (size_t)3 * n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0;
+    RT_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    ctx->renderMs = ms;
     rt_timer_resolve(ctx);
     return check_error_flag(ctx);
 }

@@ -128,8 +128,15 @@ def test_traversal_stress_10m(core, oracle, soup10m):
     got = core.trace_rays(o, d)
     ms = core.stats()["renderMs"]
     again = core.trace_rays(o, d)
+    core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 0)                                 # the reference's walk: every box the ray passes
+    core.reset_stats()
+    every_box = core.trace_rays(o, d)
+    ms_every_box = core.stats()["renderMs"]
+    core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 1)
+    print(f"\n{n} incoherent rays through 10 M triangles: {ms:.2f} ms, entering every box {ms_every_box:.2f} ms")
     for k in ("t", "triangle", "u", "v"):
         assert got[k].tobytes() == again[k].tobytes()                              # idempotent
+        assert got[k].tobytes() == every_box[k].tobytes(), k                       # boxes beyond the closest hit hold nothing closer
     hit = got["triangle"] != 0xFFFFFFFF
     assert hit.mean() > 0.5 and np.isinf(got["t"][~hit]).all()
     assert (got["t"][hit] > 0).all() and (got["u"][hit] >= 0).all() and (got["v"][hit] >= 0).all()
@@ -146,6 +153,7 @@ def test_traversal_stress_10m(core, oracle, soup10m):
     want = oracle.Oracle(sc).build().trace(o[pick], d[pick])
     H.assert_bits_equal(got["triangle"][pick], want["triangle"], "stress first-hit ids")
     H.assert_bits_equal(got["t"][pick], want["t"], "stress distances")
+    assert ms > 0 and ms_every_box > 0
     print(f"\n10M soup: {n} incoherent rays in {ms:.2f} ms = {n / ms / 1e3:.1f} Mrays/s")
 
 
