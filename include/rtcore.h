@@ -433,8 +433,10 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *                          holds.  The reference enters every box the ray passes (BVHRayTracing.cginc:87-123 has no
  *                          distance test) and keeps the closest hit; a triangle in a box left out lies behind the hit
  *                          already held, so the hit returned is the same -- up to this: a hit's distance and a box's
- *                          entry distance are separate float computations, and for a ray within about 1e-5 rad of a
- *                          large triangle's plane Moller-Trumbore's distance can be off by more than the 1/64 of room.
+ *                          entry distance are separate float computations, and Moller-Trumbore's distance has a relative
+ *                          error of about 5e-7 / (angle between ray and triangle plane x sine of the angle between the
+ *                          triangle's edges): it exceeds the 1/64 of room for a ray within 3e-5 rad of the plane of a
+ *                          well-shaped triangle it hits, within 3e-3 rad for a sliver with edges 0.6 degrees apart.
  *                          No such ray turned up in any test (the full-size frames are bit-identical on and off);
  *                          0 = the reference's walk, box for box (the one whose work counters, rt_enable_counters,
  *                          equal the CPU checker's).

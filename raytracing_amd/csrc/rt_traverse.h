@@ -315,7 +315,8 @@ struct WalkState {
 // +inf.  A triangle in a box left out lies, to rounding, behind the hit the ray already holds and could not replace
 // it; "to rounding" is where this differs from the reference's walk, which enters every box the ray passes: the two
 // return different hits only if Moller-Trumbore puts a triangle more than 1.5 % nearer than the box that holds it,
-// which takes a ray within 1e-5 rad of the triangle's plane.
+// which takes a ray within 3e-5 rad of the triangle's plane (more for slivers: the bound is 5e-7 / (that angle x the
+// sine of the angle between the triangle's edges) relative).
 template <uint32_t OCT, bool COUNT, bool NEAR>
 __device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySlab &slab, WalkState &w, uint32_t *stk, uint32_t *pend,
                                            uint32_t *spill, const uint32_t spillLanes, uint32_t cnt[3], const bool feedExhausted,
