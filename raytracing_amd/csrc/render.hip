@@ -224,8 +224,13 @@ struct ShadowSrc {
 // the walker by itself; they are listed apart from k_traverse<ShadowSrc>'s.
 struct ShadowSrcOverlapped : ShadowSrc {};
 
+// Six blocks per compute unit (six waves per SIMD): the walk is a chain of dependent fetches, so what it gains from a
+// sixth wave to switch to (the image 99.5 -> 95.5 ms) is more than what it loses by keeping a few kernel constants
+// (the spill-area pointer, source pointers) in scratch memory instead of registers: 80 registers per lane instead of
+// 89, 28 bytes of scratch, none of it touched inside the node or triangle loops.  Seven (72 registers, 12 stack
+// levels in LDS) is far slower: 118.7 ms.
 template <bool COUNT, class Src>
-__global__ __launch_bounds__(TRV_THREADS) void k_traverse(RtSceneView sv, Src src, uint32_t *__restrict__ cursor)
+__global__ __launch_bounds__(TRV_THREADS, 6) void k_traverse(RtSceneView sv, Src src, uint32_t *__restrict__ cursor)
 {
     __shared__ uint32_t lds[TRV_LDS_WORDS];
     traverse_rays<COUNT>(sv, src, cursor, lds);

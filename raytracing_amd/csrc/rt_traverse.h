@@ -68,9 +68,12 @@
 #define TRV_REDO 0xFFFFFFFEu    // in WalkState::tos of a lane whose node is TRV_DONE: this ray takes the exact, stackless walk next
 #define TRV_LDS_WORDS ((TRV_STACK_LDS + TRV_PEND_CAP) * TRV_THREADS)
 static_assert(TRV_LDS_WORDS * 4 * 6 <= 160 * 1024, "six blocks per CU must fit the LDS");
-#define TRV_BLOCKS_PER_CU 8u    // blocks launched per CU; five are resident at a time (88-96 registers per lane, 26 KB of LDS per
-                                // block), the others start when those end and find the queue empty (a grid of exactly
-                                // 5 per CU runs as fast, 7/8 of that 6 % slower)
+#ifndef TRV_BLOCKS_PER_CU
+#define TRV_BLOCKS_PER_CU 6u    // blocks launched per CU: as many as are resident at a time (80 registers per lane, 26 KB of
+                                // LDS per block); with 8 the last two start when the others end and find the queue empty
+                                // (95.5 instead of 94.9 ms per image)
+#endif
+static_assert(TRV_BLOCKS_PER_CU * TRV_THREADS * RT_STACK_DEPTH <= RT_SPILL_WORDS_PER_CU, "a spill area holds every stack level of every lane of a launch");
 
 // The reference's slab test, verbatim: true divisions, min/max that return the
 // non-NaN operand (v_min_f32 / v_max_f32 in IEEE mode).
