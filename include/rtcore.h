@@ -440,6 +440,14 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *                          No such ray turned up in any test (the full-size frames are bit-identical on and off);
  *                          0 = the reference's walk, box for box (the one whose work counters, rt_enable_counters,
  *                          equal the CPU checker's).
+ *   RT_OPT_SHARE_LONG_WALKS 1 (default): a walker launch lasts as long as its longest ray, a chain of dependent fetches
+ *                          that can run to thousands of steps.  Once a launch has no rays left to deal, lanes of a wave
+ *                          that have run out of rays take over stacked subtrees of the lanes that are still walking
+ *                          (the entries of a ray's stack are independent, and no result depends on the order they are
+ *                          walked in: the closest hit wins, equal distances go to the triangle the reference meets
+ *                          first) and hand their hit back when done.  Same results bit for bit.  Off while counters
+ *                          are enabled (a ray that may stop at its first hit would be counted differently from run to
+ *                          run).
  *   RT_OPT_OVERLAP_AFTER   0..6, default 0: the bounce whose extend launch the overlap starts after (0: as soon as the
  *                          primary hits are known)
  *   RT_OPT_OVERLAP_CUS     compute units the bounce launches keep meanwhile, default 64 (multiples of 32 measured best);
@@ -458,6 +466,7 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
 #define RT_OPT_CASTER_BOX 10
 #define RT_OPT_EAGER_SHADOWMAP 11
 #define RT_OPT_PRUNE_BY_DISTANCE 12
+#define RT_OPT_SHARE_LONG_WALKS 13
 int rt_set_option(RtContext *ctx, int option, int value);
 
 /* ------------------------------------------------------------------- stats */

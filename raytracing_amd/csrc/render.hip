@@ -704,6 +704,7 @@ RtSceneView rt_scene_view(RtContext *ctx)
     sv.stackSpill = ctx->dStackSpill + (size_t)ctx->spillArea * ctx->numCU * RT_SPILL_WORDS_PER_CU;
     sv.errorFlag = ctx->dErrorFlag;
     sv.pruneScale = ctx->optPruneByDistance ? RT_PRUNE_SCALE : rt_inf();
+    sv.shareWalks = ctx->optShareLongWalks ? 1u : 0u;
     return sv;
 }
 

@@ -84,6 +84,7 @@ struct RtSceneView {
     uint32_t cubeSize;
     uint32_t *stackSpill;      // deep stack levels of the one-ray-per-lane walker
     float pruneScale;          // a box whose entry distance exceeds (closest hit so far) x this is not entered; +inf: none is left out
+    uint32_t shareWalks;       // non-zero: at the end of a launch idle lanes take over stacked subtrees of lanes that still walk
     unsigned long long *stats; // 8 counters or nullptr
     uint32_t *errorFlag;
 };
@@ -216,6 +217,7 @@ struct RtContext {
     bool optFirstHitShadow = true;        // shadow rays that cannot meet a non-casting triangle stop at their first hit
     bool optOverlapShadow = true;         // walk the shadow rays while the later bounces run (render.hip, overlap_fork)
     bool optPruneByDistance = true;       // boxes beyond the closest hit found so far are not entered (RT_OPT_PRUNE_BY_DISTANCE)
+    bool optShareLongWalks = true;        // idle lanes take over parts of the walks a launch ends with (RT_OPT_SHARE_LONG_WALKS)
     bool optEagerShadowMap = true;        // rt_dispatch starts the ShadowMap pass of its frame (render.hip, rt_dispatch_impl)
     int eagerShadow = 0;                  // RT_EAGER_*: what rt_dispatch left for rt_dispatch_shadowmap
     uint32_t optOverlapAfter = 0;         // ... from the extend launch of this bounce on

@@ -64,6 +64,15 @@
 // much room, because the distance of a hit (Moller-Trumbore) and the entry distance of a box (slab test) are two
 // different float computations and only agree to rounding.
 #define RT_PRUNE_SCALE 1.015625f
+// Long walks are shared out at the end of a launch (RT_OPT_SHARE_LONG_WALKS, traverse_rays): once the launch has no
+// more rays to deal and at least this many lanes of a wave are idle, idle lanes take over stacked subtrees of lanes that
+// are still walking; the node phase then ends after at most TRV_SHARE_TRIPS steps so that the hand-over comes round.
+#ifndef TRV_SHARE_MIN_IDLE
+#define TRV_SHARE_MIN_IDLE 8u
+#endif
+#ifndef TRV_SHARE_TRIPS
+#define TRV_SHARE_TRIPS 16u
+#endif
 #define TRV_DONE 0xFFFFFFFFu
 #define TRV_REDO 0xFFFFFFFEu    // in WalkState::tos of a lane whose node is TRV_DONE: this ray takes the exact, stackless walk next
 #define TRV_LDS_WORDS ((TRV_STACK_LDS + TRV_PEND_CAP) * TRV_THREADS)
@@ -207,6 +216,10 @@ __device__ __forceinline__ void flush_counters(const RtSceneView &sv, uint32_t r
 // registers).
 __device__ __forceinline__ uint32_t wave_uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
+// the value lane `from` (wave-uniform) holds
+__device__ __forceinline__ uint32_t lane_value(uint32_t x, uint32_t from) { return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)from); }
+__device__ __forceinline__ float lane_value(float x, uint32_t from) { return __uint_as_float(lane_value(__float_as_uint(x), from)); }
+
 struct RayFeed {
     uint32_t *cursor;
     uint32_t total, next, end, chunk, waves2;    // wave-uniform
@@ -300,6 +313,13 @@ __device__ __forceinline__ void exact_walk(const RtSceneView &sv, const rt_f3 o,
     }
 }
 
+#ifdef TRV_SHARE_STATS            // diagnostics of the end of a launch (tools/exp_share.py): node-phase trips and busy lanes of a wave after the feed ran dry
+#define TRV_SHARE_STATS_PARAM , unsigned long long *shStat
+#define TRV_SHARE_STATS_ARG , shStat
+#else
+#define TRV_SHARE_STATS_PARAM
+#define TRV_SHARE_STATS_ARG
+#endif
 // Per-lane state of the walk through the half-float nodes.
 struct WalkState {
     uint32_t node, sp, npend, tos, below;
@@ -323,13 +343,20 @@ struct WalkState {
 template <uint32_t OCT, bool COUNT, bool NEAR>
 __device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySlab &slab, WalkState &w, uint32_t *stk, uint32_t *pend,
                                            uint32_t *spill, const uint32_t spillLanes, uint32_t cnt[3], const bool feedExhausted,
-                                           const float limit)
+                                           const float limit, const uint32_t shareTrips TRV_SHARE_STATS_PARAM)
 {
+    // shareTrips (wave-uniform): steps this phase may take while lanes idle that could take over part of a walk
+    // (0xFFFFFFFF: no such limit)
+    uint32_t trips = 0;
     for (;;) {
         const bool act = w.node != TRV_DONE && w.npend <= TRV_PEND_CAP - 2;
         const uint32_t nAct = (uint32_t)__popcll(__ballot(act));
         const uint32_t nBusy = (uint32_t)__popcll(__ballot(w.node != TRV_DONE));
         if (nAct == 0u || nAct * TRV_WALK_DEN < nBusy * TRV_WALK_NUM || (!feedExhausted && nBusy < 64u - TRV_REFILL_MIN)) break;
+        if (nBusy <= 64u - TRV_SHARE_MIN_IDLE && ++trips > shareTrips) break;
+#ifdef TRV_SHARE_STATS
+        if (feedExhausted) { shStat[0]++; shStat[1] += nBusy; }
+#endif
         if (act) {
             const uint4 *np = (const uint4 *)(sv.qnodes + w.node);
             uint4 qa = np[0], qb = np[1];
@@ -424,6 +451,18 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
     bool hasRay = false;
     uint32_t firstHit = 0;      // does this ray's first hit settle its answer: 0 not asked yet, 1 yes, 2 no
     uint32_t rayIdx = 0;
+    // Sharing a long walk (see share_out below).  Per lane: bits 0-5 the lowest stack level that still holds a subtree
+    // of its own (the levels from 1 up to there were given away and hold TRV_DONE), bits 8-14 how many lanes still
+    // walk a subtree it gave them, bit 24 "this lane walks a subtree another lane gave it", bits 16-21 that lane.
+    uint32_t share = 1u;
+#ifdef TRV_SHARE_STATS
+    unsigned long long shT0 = 0ull, shGiven = 0ull, shIters = 0ull;   // wave-uniform: clock when the feed ran dry, hand-overs, trips of the main loop since
+    unsigned long long shStat[2] = {0ull, 0ull}, shClk[4] = {0ull, 0ull, 0ull, 0ull}, shMark = 0ull;   // clocks after the feed ran dry: hand-over, node phase, triangle phase, the rest
+#define TRV_SHARE_CLK(k) if (feed.exhausted) { const unsigned long long now_ = clock64(); shClk[k] += now_ - shMark; shMark = now_; }
+#else
+#define TRV_SHARE_CLK(k)
+#endif
+    const bool sharing = !COUNT && sv.shareWalks != 0u;
     WalkState w;
     w.node = TRV_DONE; w.sp = 0; w.npend = 0; w.tos = TRV_DONE; w.below = TRV_DONE; w.popped = false;
     rt_f3 o = rt_splat3(0.0f), d = rt_splat3(0.0f), r = rt_splat3(0.0f);
@@ -455,6 +494,7 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                 h.t = rt_inf(); h.u = 0.0f; h.v = 0.0f; h.leaf = RT_INVALID;
                 hasRay = true;
                 firstHit = 0;
+                share = 1u;
                 stk[0] = TRV_DONE;                             // what the last pop of a ray returns
                 w.sp = 1;
                 w.tos = TRV_DONE;
@@ -472,6 +512,64 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                 }
             }
         }
+        // ---- the end of a launch: idle lanes take over stacked subtrees of the lanes that are still walking.
+        // A launch lasts as long as its longest ray, a chain of dependent fetches (the longest camera rays of a
+        // finely tessellated scene take thousands of steps, most of a millisecond during which the chip idles), but
+        // the entries of a ray's stack are independent subtrees and no result depends on the order they are walked in:
+        // the closest hit wins, equal distances go by leafRank, and for a ray that may stop at its first hit any hit
+        // will do.  So once the launch has no rays left to deal, a lane without a ray copies the ray and the hit so
+        // far of a lane that walks, takes the BOTTOM entry of its stack (the subtree it would reach last) and leaves
+        // TRV_DONE there -- the giver's walk then ends when it pops down to that level, as all below was given away
+        // too.  The level taken is never the giver's top one, which it mirrors in a register.  A taker may give
+        // in turn.  When a taker's walk ends its hit goes back to the giver (deliver, below), and a giver's ray
+        // retires when its own walk and all it gave away are done.
+        uint32_t shareTrips = 0xFFFFFFFFu;
+#ifdef TRV_SHARE_STATS
+        if (feed.exhausted && shT0 == 0ull) shT0 = shMark = clock64();
+        if (feed.exhausted) shIters++;
+        TRV_SHARE_CLK(3)
+#endif
+        if (sharing && feed.exhausted) {
+            shareTrips = TRV_SHARE_TRIPS;
+            const uint32_t lowest = share & 63u;
+            unsigned long long give = __ballot(hasRay && w.node != TRV_DONE && lowest + 2u <= w.sp && lowest < TRV_STACK_LDS);
+            unsigned long long take = __ballot(!hasRay);
+            if (give != 0ull && (uint32_t)__popcll(take) >= TRV_SHARE_MIN_IDLE) {
+                while (give != 0ull && take != 0ull) {
+                    const uint32_t D = (uint32_t)__ffsll((long long)give) - 1u, T = (uint32_t)__ffsll((long long)take) - 1u;   // wave-uniform
+                    give &= give - 1ull;
+                    take &= take - 1ull;
+                    const float gox = lane_value(o.x, D), goy = lane_value(o.y, D), goz = lane_value(o.z, D);
+                    const float gdx = lane_value(d.x, D), gdy = lane_value(d.y, D), gdz = lane_value(d.z, D);
+                    const float gt = lane_value(h.t, D), gu = lane_value(h.u, D), gv = lane_value(h.v, D);
+                    const uint32_t gleaf = lane_value(h.leaf, D), gfirst = lane_value(firstHit, D);
+                    const uint32_t level = lane_value(share, D) & 63u;
+                    if (lane == T) {
+                        o = rt_mk3(gox, goy, goz);
+                        d = rt_mk3(gdx, gdy, gdz);
+                        r = rt_mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        slab = rt_ray_slab(sv.grid, o, r);
+                        h.t = gt; h.u = gu; h.v = gv; h.leaf = gleaf;
+                        firstHit = gfirst;
+                        uint32_t *entry = lds + level * TRV_THREADS + (threadIdx.x & ~63u) + D;
+                        w.node = *entry;
+                        *entry = TRV_DONE;
+                        stk[0] = TRV_DONE;
+                        w.sp = 1;
+                        w.tos = TRV_DONE;
+                        w.popped = false;
+                        w.npend = 0;
+                        hasRay = true;
+                        share = 1u | (D << 16) | (1u << 24);
+                    }
+                    if (lane == D) share += 1u + (1u << 8);
+#ifdef TRV_SHARE_STATS
+                    shGiven++;
+#endif
+                }
+            }
+        }
+        TRV_SHARE_CLK(0)
         if (__ballot(hasRay) == 0ull) break;
         TRV_PHASE(0)
 #ifdef TRV_PROFILE
@@ -487,15 +585,15 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
             constexpr bool NEAR = true;                              // every kind of ray gains: a hit found sooner, or a closer one
             const float limit = h.t * sv.pruneScale;                 // +inf without a hit, or with the option off
             switch (oct) {
-            case 0: node_phase<0, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;
-            case 1: node_phase<1, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;
-            case 2: node_phase<2, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;
-            case 3: node_phase<3, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;
-            case 4: node_phase<4, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;
-            case 5: node_phase<5, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;
-            case 6: node_phase<6, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;
-            case 7: node_phase<7, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;
-            default: node_phase<8, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit); break;
+            case 0: node_phase<0, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips TRV_SHARE_STATS_ARG); break;
+            case 1: node_phase<1, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips TRV_SHARE_STATS_ARG); break;
+            case 2: node_phase<2, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips TRV_SHARE_STATS_ARG); break;
+            case 3: node_phase<3, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips TRV_SHARE_STATS_ARG); break;
+            case 4: node_phase<4, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips TRV_SHARE_STATS_ARG); break;
+            case 5: node_phase<5, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips TRV_SHARE_STATS_ARG); break;
+            case 6: node_phase<6, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips TRV_SHARE_STATS_ARG); break;
+            case 7: node_phase<7, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips TRV_SHARE_STATS_ARG); break;
+            default: node_phase<8, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips TRV_SHARE_STATS_ARG); break;
             }
         }
 
@@ -510,6 +608,7 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
         }
 
         TRV_PHASE(1)
+        TRV_SHARE_CLK(1)
         // ---- triangle phase: every lane tests its queued triangles in the order it met them
         const uint32_t npend = w.npend;
         if (COUNT) {
@@ -557,15 +656,54 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
             if (firstHit == 1u) w.node = TRV_DONE;             // retired below
         }
         TRV_PHASE(2)
+        TRV_SHARE_CLK(2)
 
-        // ---- retire finished rays
-        if (hasRay && w.node == TRV_DONE) {
+        // ---- subtrees that were taken over and are done: the hit goes back to the lane that gave the subtree away,
+        //      which keeps it if it is closer than its own, or as close and earlier in the reference's order
+        if (sharing && feed.exhausted) {
+            for (;;) {
+                const unsigned long long fin = __ballot(hasRay && w.node == TRV_DONE && (share & 0x01007F00u) == 0x01000000u);
+                if (fin == 0ull) break;
+                const uint32_t T = (uint32_t)__ffsll((long long)fin) - 1u;                 // wave-uniform
+                const uint32_t giver = (lane_value(share, T) >> 16) & 63u;
+                const float ct = lane_value(h.t, T), cu = lane_value(h.u, T), cv = lane_value(h.v, T);
+                const uint32_t cleaf = lane_value(h.leaf, T);
+                if (lane == giver) {
+                    if (cleaf != RT_INVALID && cleaf != h.leaf) {
+                        bool closer = ct < h.t;
+                        if (ct == h.t && h.leaf != RT_INVALID) closer = sv.leafRank[cleaf] < sv.leafRank[h.leaf];
+                        if (closer) { h.t = ct; h.u = cu; h.v = cv; h.leaf = cleaf; }
+                    }
+                    share -= 1u << 8;
+                }
+                if (lane == T) {
+                    hasRay = false;
+                    share = 1u;
+                }
+            }
+        }
+        // ---- retire finished rays (one that gave subtrees away waits for them)
+        if (hasRay && w.node == TRV_DONE && (share & 0x01007F00u) == 0u) {
             src.store(rayIdx, h);
             if (COUNT && h.leaf != RT_INVALID) nHits++;
             hasRay = false;
         }
         TRV_PHASE(3)
     }
+#ifdef TRV_SHARE_STATS
+    if (lane == 0) {             // [28] hand-overs, [29] waves, [30] sum and [31] maximum of a wave's clocks after the feed ran dry
+        const unsigned long long tail = shT0 ? clock64() - shT0 : 0ull;
+        atomicAdd(&sv.stats[28], shGiven);
+        atomicAdd(&sv.stats[29], 1ull);
+        atomicAdd(&sv.stats[30], tail);
+        atomicMax(&sv.stats[31], tail);
+        // of the wave that went on longest: its node-phase trips, the busy lanes summed over them, main-loop trips and hand-overs
+        atomicMax(&sv.stats[27], (tail >> 8) << 32 | (shStat[0] & 0xFFFFFFFFull));
+        atomicMax(&sv.stats[26], (tail >> 8) << 32 | (shStat[1] & 0xFFFFFFFFull));
+        atomicMax(&sv.stats[25], (tail >> 8) << 32 | (shIters & 0xFFFFull) << 16 | (shGiven & 0xFFFFull));
+        for (int k = 0; k < 4; ++k) atomicMax(&sv.stats[21 + k], (tail >> 8) << 32 | (shClk[k] & 0xFFFFFFFFull));
+    }
+#endif
 #ifdef TRV_PROFILE
     if (lane == 0) {
         for (int k = 0; k < 4; ++k) atomicAdd(&sv.stats[16 + k], pT[k]);

@@ -305,6 +305,72 @@ def test_shadow_rays_walked_while_the_bounces_run_do_not_change_a_bit(core):
         H.assert_bits_equal(images[0][1], images[k][1], f"shadow map, overlap variant {k}")
 
 
+def test_long_walks_shared_between_lanes_do_not_change_a_bit(core, oracle):
+    """At the end of a launch lanes that have run out of rays take over stacked subtrees of the lanes that still
+    walk and hand their hit back (RT_OPT_SHARE_LONG_WALKS).  Launches of few rays are all end: closest hits of
+    incoherent rays through the car and a soup, on against off against the checker's walk of the reference's tree,
+    in the ordinary library and in the one that keeps two stack levels in LDS (where only the bottom level can be
+    handed over, and stacks that run out restart on the stackless walk); then frames with the ShadowMap pass, whose
+    rays may stop at their first hit."""
+    import os
+    from raytracing_amd import native
+    libs = [("librtcore.so", core, False)]
+    path = os.path.join(os.path.dirname(native.LIB_PATH), "librtcore_spill2.so")
+    if os.path.exists(path):
+        libs.append(("librtcore_spill2.so", native.RtCore(0, lib_path=path), True))
+    try:
+        for sc_name, sc in (("car", scenes.car_standin(96, 64, detail=0.05)), ("soup", scenes.triangle_soup(20000, seed=5))):
+            v = np.asarray(sc.vertices["position"], np.float32).reshape(-1, 3)
+            lo, hi = v.min(axis=0), v.max(axis=0)
+            rs = np.random.Generator(np.random.PCG64(31))
+            rays = []
+            for n in (7, 64, 700, 5000):                       # from one wave with most lanes idle to a few waves per unit
+                o = (lo + (hi - lo) * rs.random((n, 3))).astype(np.float32)
+                t = (lo + (hi - lo) * rs.random((n, 3))).astype(np.float32)
+                d = t - o
+                d /= np.linalg.norm(d, axis=1, keepdims=True)
+                rays.append((o, d.astype(np.float32)))
+            orc = oracle.Oracle(sc).build()
+            for lib_name, c, _ in libs:
+                c.upload(sc)
+                c.bvh_build()
+                for o, d in rays:
+                    want = orc.trace(o, d)
+                    for prune in (1, 0):
+                        c.set_option(wire.OPT_PRUNE_BY_DISTANCE, prune)
+                        for on in (1, 0):
+                            c.set_option(wire.OPT_SHARE_LONG_WALKS, on)
+                            got = c.trace_rays(o, d)
+                            for k in ("triangle", "t", "u", "v"):
+                                H.assert_bits_equal(got[k], want[k], f"{sc_name}, {lib_name}, {len(o)} rays, sharing {on}, pruning {prune}: {k}")
+                c.set_option(wire.OPT_PRUNE_BY_DISTANCE, 1)
+                c.set_option(wire.OPT_SHARE_LONG_WALKS, 1)
+        sc = scenes.car_standin(96, 64, detail=0.05)
+        seeds = scenes.frame_seeds(3, seed=5)
+        images = []
+        for lib_name, c, _ in libs:
+            c.upload(sc)
+            c.bvh_build()
+            c.set_params(sc.params)
+            for on in (1, 0):
+                c.set_option(wire.OPT_SHARE_LONG_WALKS, on)
+                for frames in (seeds, seeds[:1]):              # a batch, and one frame in flight
+                    c.set_dirty()
+                    c.render_frames(frames)
+                    images.append((f"{lib_name}, sharing {on}, {len(frames)} frame(s)", len(frames),
+                                   c.readback(wire.IMAGE_CONVERGED), c.readback(wire.IMAGE_SHADOWMAP)))
+            c.set_option(wire.OPT_SHARE_LONG_WALKS, 1)
+        for label, n, conv, sm in images[1:]:
+            ref = next(im for im in images if im[1] == n)
+            H.assert_bits_equal(conv, ref[2], f"converged image, {label}")
+            H.assert_bits_equal(sm, ref[3], f"shadow map, {label}")
+        assert (images[0][3][..., 0] < 1).any()
+    finally:
+        for _, c, own in libs:
+            if own:
+                c.close()
+
+
 @pytest.mark.parametrize("non_casters", ["ground only", "a third of the car", "none", "all", "a flat sheet under the car",
                                          "ground only, light in the xy plane", "ground only, wide light"])
 def test_shadow_rays_that_stop_at_their_first_hit_do_not_change_a_bit(core, non_casters):

@@ -310,6 +310,7 @@ def test_car_1080p_execution_options_do_not_change_a_bit(core):
         core.set_option(wire.OPT_OVERLAP_SHADOW, fast)
         core.set_option(wire.OPT_MATERIAL_SORT, fast)
         core.set_option(wire.OPT_PRUNE_BY_DISTANCE, fast)
+        core.set_option(wire.OPT_SHARE_LONG_WALKS, fast)
         core.set_option(wire.OPT_BATCH_FRAMES, 0 if fast else 8)
         core.set_dirty()
         core.render_frames(seeds)

@@ -21,7 +21,7 @@ for kv in filter(None, os.environ.get("RT_OPTS", "").split(",")):     # rt_set_o
 seeds = scenes.frame_seeds(spp, 1)
 core.render_frames(seeds)
 out = []
-for _ in range(3):
+for _ in range(int(os.environ.get("REPS", "3"))):
     core.set_dirty(); core.render_frames(seeds)
     out.append(round(core.stats()["renderMs"], 2))
 print(json.dumps({"world": world, "spp": spp, "ms_per_image_of_this_rank": out}))
