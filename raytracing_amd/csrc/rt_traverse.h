@@ -216,6 +216,16 @@ __device__ __forceinline__ void flush_counters(const RtSceneView &sv, uint32_t r
 // registers).
 __device__ __forceinline__ uint32_t wave_uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
+// How many lanes of a ballot are set, as a 32-bit scalar the compiler cannot see through: it knows the population
+// count of a 64-bit mask as a 64-bit number, and scalar code has no ordered 64-bit comparison, so every `<` on such a
+// count in a loop test became a vector instruction (three per step of the node phase).
+__device__ __forceinline__ uint32_t lane_count(unsigned long long mask)
+{
+    uint32_t n;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(mask) : "scc");
+    return n;
+}
+
 // the value lane `from` (wave-uniform) holds
 __device__ __forceinline__ uint32_t lane_value(uint32_t x, uint32_t from) { return (uint32_t)__builtin_amdgcn_readlane((int)x, (int)from); }
 __device__ __forceinline__ float lane_value(float x, uint32_t from) { return __uint_as_float(lane_value(__float_as_uint(x), from)); }
@@ -349,9 +359,12 @@ __device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySla
     // (0xFFFFFFFF: no such limit)
     uint32_t trips = 0;
     for (;;) {
-        const bool act = w.node != TRV_DONE && w.npend <= TRV_PEND_CAP - 2;
-        const uint32_t nAct = (uint32_t)__popcll(__ballot(act));
-        const uint32_t nBusy = (uint32_t)__popcll(__ballot(w.node != TRV_DONE));
+        // (one ballot per comparison, combined as scalar masks: the ballot of a conjunction is made by way of a vector register)
+        const bool busy = w.node != TRV_DONE, room = w.npend <= TRV_PEND_CAP - 2;
+        const bool act = busy && room;
+        const unsigned long long busyMask = __ballot(busy);
+        const uint32_t nAct = lane_count(busyMask & __ballot(room));
+        const uint32_t nBusy = lane_count(busyMask);
         if (nAct == 0u || nAct * TRV_WALK_DEN < nBusy * TRV_WALK_NUM || (!feedExhausted && nBusy < 64u - TRV_REFILL_MIN)) break;
         if (nBusy <= 64u - TRV_SHARE_MIN_IDLE && ++trips > shareTrips) break;
 #ifdef TRV_SHARE_STATS
@@ -483,7 +496,7 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
     for (;;) {
         // ---- refill idle lanes: ballot, prefix count, one atomic per wave
         const unsigned long long idle = __ballot(!hasRay);
-        const uint32_t nIdle = (uint32_t)__popcll(idle);
+        const uint32_t nIdle = lane_count(idle);
         if (!feed.exhausted && nIdle >= TRV_REFILL_MIN) {
             const uint32_t mine = feed.draw(nIdle, hasRay ? 64u : (uint32_t)__popcll(idle & lt));
             if (mine != TRV_DONE) {

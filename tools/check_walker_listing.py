@@ -14,7 +14,8 @@ indexing memory with a wrapped stack pointer.  Which form comes out depends on s
 end test did it once, a readfirstlane round the end test another time), so the listing is looked at before a
 changed walker goes anywhere near a GPU.
 
-The check: the loop header that holds the phase test (two s_bcnt1_i32_b64 in a row) must not be the target of an
+The check: the loop header that holds the phase test (two s_bcnt1_i32_b64 within a few lines of each other, markers of inline
+assembly aside) must not be the target of an
 `s_cbranch_execnz` -- that branch is the inner loop's "some lanes stepped, go round again without the others".
 """
 import os
@@ -48,8 +49,12 @@ def functions(text):
 def check_function(lines):
     """-> (number of phase-test loops, [header labels built the wrong way])"""
     bad, loops = [], 0
+    lines = [x for x in lines if not x.strip().startswith(";;#ASM")]     # the counts are made in inline assembly (lane_count)
+    skip = -1
     for i in range(len(lines) - 1):
-        if "s_bcnt1_i32_b64" in lines[i] and "s_bcnt1_i32_b64" in lines[i + 1]:
+        second = [k for k in range(i + 1, min(i + 5, len(lines))) if "s_bcnt1_i32_b64" in lines[k]]
+        if i > skip and "s_bcnt1_i32_b64" in lines[i] and second:      # the two counts, at most a few scalar instructions apart
+            skip = second[0]
             header = None
             for j in range(i, max(i - 60, -1), -1):               # nearest loop header above the test
                 m = re.match(r"^(\.LBB\d+_\d+):", lines[j])
