@@ -68,7 +68,7 @@
 // more rays to deal and at least this many lanes of a wave are idle, idle lanes take over stacked subtrees of lanes that
 // are still walking; the node phase then ends after at most TRV_SHARE_TRIPS steps so that the hand-over comes round.
 #ifndef TRV_SHARE_MIN_IDLE
-#define TRV_SHARE_MIN_IDLE 8u
+#define TRV_SHARE_MIN_IDLE 32u
 #endif
 #ifndef TRV_SHARE_TRIPS
 #define TRV_SHARE_TRIPS 16u

@@ -37,6 +37,15 @@ def test_device_rand_stream(core, oracle, px, py, seed):
     H.assert_bits_equal(got, want, "Rand() stream")
 
 
+def test_device_rand_stream_against_an_independent_restatement(core):
+    """The same stream against tests/independent.py, which shares no source with the library (the checker does)."""
+    from tests import independent
+    for px, py, seed in ((1, 1, 0.25), (7, 3, 0.25), (1919, 1079, 0.25), (3839, 2159, 0.73), (640, 360, 17.0), (0, 5, 0.25)):
+        want, _ = independent.rand_sequence(px, py, seed, 128)
+        got = core.debug_eval(7, np.array([px, py], np.float32), np.array([seed], np.float32), n=128)
+        H.assert_bits_equal(got, want, f"Rand() stream of pixel ({px}, {py}), seed {seed}")
+
+
 def _scene(name):
     if name == "cornell":
         return scenes.cornell_box(64, 64, sphere_segments=32)

@@ -322,6 +322,23 @@ def test_golden_rand_and_math(oracle):
         assert oracle.math(which, a, b).view(np.uint32).tolist() == m[name], name
 
 
+def test_rand_stream_against_an_independent_restatement(oracle):
+    """The checker and the kernels take SetSeed / Rand from one header (include/rt_math.h), so comparing the two says
+    nothing about the header.  tests/independent.py restates Header.cginc:66-92 from the shader text in numpy binary32
+    arithmetic with libm's sin: 400 random pixels and seeds, 64 draws each, every value and every state bit for bit.
+    (The header's sin is within 0.51 ulp of libm's; a last-bit difference would have to survive being added to a
+    number of up to 4e9 to show, and none does in this sample.)"""
+    from tests import independent
+    rs = np.random.Generator(np.random.PCG64(3))
+    for _ in range(400):
+        px, py = int(rs.integers(0, 3840)), int(rs.integers(0, 2160))
+        seed = float(np.float32(rs.uniform(0, 500)))
+        want_v, want_s = independent.rand_sequence(px, py, seed, 64)
+        got_v, got_s = oracle.rand_sequence(px, py, seed, 64)
+        assert got_s.tolist() == want_s.tolist(), (px, py, seed)
+        assert got_v.view(np.uint32).tolist() == want_v.view(np.uint32).tolist(), (px, py, seed)
+
+
 def test_rand_is_uniform_enough(oracle):
     vals = np.concatenate([oracle.rand_sequence(px, py, 0.37, 64)[0] for px in range(3, 40) for py in range(5, 30)])
     assert abs(vals.mean() - 0.5) < 0.02 and abs(np.mean(vals < 0.25) - 0.25) < 0.02

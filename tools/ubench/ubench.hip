@@ -85,6 +85,25 @@ __global__ __launch_bounds__(256) void k_gather(const uint4 *__restrict__ table,
     out[blockIdx.x * 256u + threadIdx.x] = acc + idx;
 }
 
+// One wave alone on the chip: shader clocks per step of a dependent 16-byte gather with `lanes` active lanes, each
+// following its own chain through the table (how long a step of a lone walker wave takes by the lanes that still walk).
+__global__ __launch_bounds__(64) void k_lone_wave(const uint4 *__restrict__ table, uint32_t mask, uint32_t steps, uint32_t lanes, uint32_t seed, unsigned long long *clocks, uint32_t *out)
+{
+    uint32_t idx = (threadIdx.x + 1u + seed) * 2654435761u;     // another chain every launch: nothing of it is in a cache yet
+    uint32_t acc = 0;
+    const unsigned long long t0 = clock64();
+    if (threadIdx.x < lanes) {
+        for (uint32_t s = 0; s < steps; ++s) {
+            const uint4 a = table[(size_t)(idx & mask) * 2];
+            acc += a.y;
+            idx = idx * 1664525u + a.x + 1013904223u;
+        }
+    }
+    const unsigned long long t1 = clock64();
+    out[threadIdx.x] = acc + idx;
+    if (threadIdx.x == 0) *clocks = t1 - t0;
+}
+
 static double run(void (*launch)(void *), void *arg)
 {
     hipEvent_t e0, e1;
@@ -101,8 +120,38 @@ static double run(void (*launch)(void *), void *arg)
     return ms;
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 1 && argv[1][0] == 'l') {          // ubench lone: a lone wave's step time by active lanes and table size
+        unsigned long long *clk;
+        uint32_t *o;
+        CHECK(hipMalloc(&clk, 8));
+        CHECK(hipMalloc(&o, 64 * 4));
+        const size_t lsizes[] = {256u << 10, 2u << 20, 16u << 20, 64u << 20, 512u << 20};
+        for (size_t bytes : lsizes) {
+            const uint32_t n = (uint32_t)(bytes / 32);
+            std::vector<uint32_t> h((size_t)n * 8);
+            uint32_t s = 12345;
+            for (auto &x : h) { s = s * 1103515245u + 12345u; x = s; }
+            uint4 *table;
+            CHECK(hipMalloc(&table, bytes));
+            CHECK(hipMemcpy(table, h.data(), bytes, hipMemcpyHostToDevice));
+            printf("lone wave, table %7zu KB: clocks per step with 1 / 2 / 4 / 8 / 16 / 32 / 64 lanes:", bytes >> 10);
+            for (uint32_t lanes = 1; lanes <= 64; lanes *= 2) {
+                unsigned long long c = 0;
+                static uint32_t seed = 0;
+                for (int rep = 0; rep < 2; ++rep) {
+                    seed += 977u;
+                    hipLaunchKernelGGL(k_lone_wave, dim3(1), dim3(64), 0, 0, table, n - 1, 512u, lanes, seed, clk, o);
+                    CHECK(hipMemcpy(&c, clk, 8, hipMemcpyDeviceToHost));
+                }
+                printf(" %llu", c / 512ull);
+            }
+            printf("\n");
+            CHECK(hipFree(table));
+        }
+        return 0;
+    }
     int cus = 0;
     CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
     const uint32_t blocks = cus * 5;          // 5 blocks of 4 waves per CU = 5 waves per SIMD
