@@ -340,6 +340,7 @@ int rt_set_params(RtContext *ctx, const RtParams *p)
     const uint32_t T = (uint32_t)tm.tilesX * (uint32_t)tm.tilesY;
     tm.nLocalTiles = T > (uint32_t)q.tileRank ? (T - (uint32_t)q.tileRank + (uint32_t)q.tileCount - 1) / (uint32_t)q.tileCount : 0;
     tm.nSlots = tm.nLocalTiles * (uint32_t)(q.tileSize * q.tileSize);
+    tm.finish();
     // ray indices are 32-bit: 16 shadow rays per path slot of one frame must fit
     if ((uint64_t)tm.nLocalTiles * (uint64_t)(q.tileSize * q.tileSize) * 16ull >= (1ull << 32))
         return rt_fail(ctx, RT_E_INVALID, "%d x %d pixels are too many for one context: split the frame into more tiles (tileCount)", q.width, q.height);
@@ -687,6 +688,9 @@ int rt_get_stats(RtContext *ctx, RtStats *out)
 
 /* The frames-in-flight rule by itself, for host-side checks (no GPU needed).  Not part of rtcore.h. */
 uint32_t rt_debug_batch_frames(uint32_t n_slots, uint32_t option, uint32_t wanted) { return rt_batch_frames_rule(n_slots, option, wanted); }
+
+/* The tile map's division by a fixed divisor by itself (RtDivisor), for host-side checks.  Not part of rtcore.h. */
+uint32_t rt_debug_divide(uint32_t n, uint32_t d, uint32_t *rem) { return rt_divisor(d).div(n, rem); }
 
 /* Phase profile of the one-ray-per-lane walker (library built with -DTRV_PROFILE): 4 clock sums
  * (refill, node, triangle, retire) and 6 counts, summed over waves.  Not part of rtcore.h. */

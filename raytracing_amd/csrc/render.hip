@@ -339,9 +339,8 @@ __global__ __launch_bounds__(Q_THREADS) void k_generate(RtTileMap tm, RtParams P
     }
     // the ray of an active path is made once its place in the queue is known, and written there
     block_queue_flush(stage, qcount, [&](uint32_t g, uint32_t at) {
-        const uint32_t frame = g / tm.nSlots, slot = g % tm.nSlots;
-        uint32_t px = 0, py = 0;
-        tm.slot_to_pixel(slot, &px, &py);
+        uint32_t frame, px = 0, py = 0;
+        tm.slot_to_pixel(tm.local_slot(g, &frame), &px, &py);
         rt_rng r;
         rt_rng_init(&r, px, py, seeds[frame]);
         const float r0 = rt_rand(&r), r1 = rt_rand(&r);
@@ -476,7 +475,8 @@ __global__ __launch_bounds__(Q_THREADS) void k_shade(RtSceneView sv, RtBruteView
                 c.P = &P;
                 const uint2 rs = rng[slot];
                 uint32_t px, py;
-                tm.slot_to_pixel(slot % tm.nSlots, &px, &py);   // global pixel coordinates feed Rand()
+                uint32_t frameOfSlot;
+                tm.slot_to_pixel(tm.local_slot(slot, &frameOfSlot), &px, &py);   // global pixel coordinates feed Rand()
                 c.rng.state = rs.x;
                 c.rng.seed = __uint_as_float(rs.y);
                 c.rng.px = (float)px;
@@ -535,7 +535,8 @@ __global__ __launch_bounds__(Q_THREADS) void k_sm_setup(RtSceneView sv, RtTileMa
             const rt_f3 origin = rt_add3(hit.position, rt_scale3(hit.normal, RT_NORMAL_BIAS));
             rt_rng r;
             uint32_t px, py;
-            tm.slot_to_pixel(slot % tm.nSlots, &px, &py);
+            uint32_t frameOfSlot;
+            tm.slot_to_pixel(tm.local_slot(slot, &frameOfSlot), &px, &py);
             const uint2 rs = rng[slot];
             r.state = rs.x;
             r.seed = __uint_as_float(rs.y);

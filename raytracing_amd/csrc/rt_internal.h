@@ -104,23 +104,66 @@ struct RtBruteView {
     uint32_t nPlanes, nSpheres, nCubes, nMeshes, nTris;
 };
 
+// Division of 32-bit numbers by a divisor fixed when the tile map is made: quotient and remainder by one multiply-high
+// and one correction instead of the thirty-odd instructions of a division by a value the compiler does not know
+// (every path of every kernel that needs its pixel's coordinates made four of those).  m = ceil(2^32 / d), so
+// floor(n * m / 2^32) is the quotient or one more; 2 <= d <= 2^31 (d = 1 is answered without the multiply).
+struct RtDivisor {
+    uint32_t d, m;
+    __host__ __device__ inline uint32_t div(uint32_t n, uint32_t *rem) const
+    {
+        if (d == 1u) { *rem = 0; return n; }
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint32_t q = __umulhi(n, m);
+#else
+        uint32_t q = (uint32_t)(((unsigned long long)n * m) >> 32);
+#endif
+        uint32_t r = n - q * d;
+        if (r >= d) { q -= 1u; r += d; }        // one too many: the remainder wrapped
+        *rem = r;
+        return q;
+    }
+};
+inline RtDivisor rt_divisor(uint32_t d)
+{
+    RtDivisor k;
+    k.d = d ? d : 1u;
+    k.m = k.d > 1u ? (uint32_t)(((1ull << 32) + k.d - 1u) / k.d) : 0u;
+    return k;
+}
+
 struct RtTileMap {
     int width, height;
     int tileSize, tilesX, tilesY;
     int rank, count;
     uint32_t nLocalTiles;
     uint32_t nSlots;           // nLocalTiles * tileSize^2
+    RtDivisor byTilePixels, byTilesX, byBlocksPerRow, bySlots;   // tileSize^2, tilesX, tileSize / 8, nSlots (finish())
 
+    void finish()
+    {
+        byTilePixels = rt_divisor((uint32_t)(tileSize * tileSize));
+        byTilesX = rt_divisor((uint32_t)tilesX);
+        byBlocksPerRow = rt_divisor((uint32_t)tileSize >> 3);
+        bySlots = rt_divisor(nSlots);
+    }
+    // path slot (frame * nSlots + tile-local pixel slot) -> tile-local pixel slot; *frame: which frame in flight
+    __host__ __device__ inline uint32_t local_slot(uint32_t pathSlot, uint32_t *frame) const
+    {
+        uint32_t slot;
+        *frame = bySlots.div(pathSlot, &slot);
+        return slot;
+    }
     __host__ __device__ inline bool slot_to_pixel(uint32_t slot, uint32_t *px, uint32_t *py) const
     {
-        const uint32_t ts2 = (uint32_t)(tileSize * tileSize);
-        const uint32_t k = slot / ts2, within = slot % ts2;
+        uint32_t within, tx, bx;
+        const uint32_t k = byTilePixels.div(slot, &within);
         const uint32_t t = k * (uint32_t)count + (uint32_t)rank;
-        const uint32_t tx = t % (uint32_t)tilesX, ty = t / (uint32_t)tilesX;
+        const uint32_t ty = byTilesX.div(t, &tx);
         const uint32_t b = within >> 6, l = within & 63u;
-        const uint32_t bpr = (uint32_t)tileSize >> 3;
-        const uint32_t x = tx * tileSize + (b % bpr) * 8 + (l & 7u);
-        const uint32_t y = ty * tileSize + (b / bpr) * 8 + (l >> 3);
+        const uint32_t by = byBlocksPerRow.div(b, &bx);
+        const uint32_t x = tx * tileSize + bx * 8 + (l & 7u);
+        const uint32_t y = ty * tileSize + by * 8 + (l >> 3);
         *px = x;
         *py = y;
         return x < (uint32_t)width && y < (uint32_t)height;

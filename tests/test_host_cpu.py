@@ -99,6 +99,28 @@ def test_batch_frames_rule_keeps_ray_indices_in_32_bits():
             assert 1 <= got <= 64 and (got == 1 or slots * got * 16 < 1 << 32), (slots, option, got)
 
 
+def test_division_by_a_divisor_fixed_with_the_tile_map():
+    """Kernels turn a path slot into pixel coordinates with one multiply-high and one correction per division
+    (RtDivisor: tile pixels, tiles per row, pixel blocks per tile row, slots per frame).  Quotient and remainder
+    must be the integer ones for every numerator below 2^32 and every divisor up to 2^31: edge numerators for many
+    divisors, and random pairs."""
+    import numpy as np
+    lib = native.load()
+    f = lib.rt_debug_divide
+    f.restype = C.c_uint32
+    f.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    rem = C.c_uint32()
+    rs = np.random.Generator(np.random.PCG64(17))
+    divisors = [1, 2, 3, 5, 7, 8, 30, 34, 60, 64, 4096, 4097, 65535, 65536, 65537, 1920 * 1080, 2088960, 8355840, (1 << 27) + 1,
+                (1 << 28) - 1, (1 << 31) - 1, 1 << 31] + [int(x) for x in rs.integers(1, 1 << 31, 200)]
+    for d in divisors:
+        edge = [0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, (1 << 32) - 1, (1 << 32) - d, ((1 << 32) // d) * d - 1, ((1 << 32) // d) * d]
+        for n in edge + [int(x) for x in rs.integers(0, 1 << 32, 60)]:
+            n = min(max(n, 0), (1 << 32) - 1)
+            q = f(n, d, C.byref(rem))
+            assert (q, rem.value) == (n // d, n % d), (n, d, q, rem.value)
+
+
 def _c_prototypes():
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rtcore.h")).read(), flags=re.S)
     protos = {}
