@@ -467,6 +467,7 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
 #define RT_OPT_EAGER_SHADOWMAP 11
 #define RT_OPT_PRUNE_BY_DISTANCE 12
 #define RT_OPT_SHARE_LONG_WALKS 13
+#define RT_OPT_WIDE_NODES 14
 int rt_set_option(RtContext *ctx, int option, int value);
 
 /* ------------------------------------------------------------------- stats */

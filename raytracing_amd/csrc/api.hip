@@ -612,6 +612,7 @@ int rt_set_option(RtContext *ctx, int option, int value)
     case RT_OPT_EAGER_SHADOWMAP: ctx->optEagerShadowMap = value != 0; return RT_OK;
     case RT_OPT_PRUNE_BY_DISTANCE: ctx->optPruneByDistance = value != 0; return RT_OK;
     case RT_OPT_SHARE_LONG_WALKS: ctx->optShareLongWalks = value != 0; return RT_OK;
+    case RT_OPT_WIDE_NODES: ctx->optWideNodes = value != 0; return RT_OK;
     case RT_OPT_PACKET_SHADOW: ctx->optPacketShadow = value != 0; return RT_OK;
     case RT_OPT_PACKET_PRIMARY: ctx->optPacketPrimary = value != 0; return RT_OK;
     case RT_OPT_PACKET_TRACE: ctx->optPacketTrace = value != 0; return RT_OK;

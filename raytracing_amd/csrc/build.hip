@@ -627,6 +627,38 @@ __global__ __launch_bounds__(256) void k_emit_qnodes(uint32_t N, const BuildPlan
     qnodes[i * 2 + 1] = make_uint4(wr[1], wr[2], l, r);
 }
 
+// Two levels per record: the places of node i hold the children of its left child, then of its right child; a child
+// that is a leaf takes one place as itself.  Boxes and references are copied from the finished 32-byte nodes.
+__global__ __launch_bounds__(256) void k_emit_wide_nodes(uint32_t NI, const uint4 *__restrict__ qnodes, uint4 *__restrict__ wnodes)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NI) return;
+    const uint4 a = qnodes[i * 2], b = qnodes[i * 2 + 1];
+    const uint32_t cbox[2][3] = {{a.x, a.y, a.z}, {a.w, b.x, b.y}}, cref[2] = {b.z, b.w};
+    uint32_t box[4][3], ref[4];
+    for (int k = 0; k < 4; ++k) {
+        box[k][0] = box[k][1] = box[k][2] = RT_QH_NO_BOX;
+        ref[k] = RT_INVALID;
+    }
+    int n = 0;
+    for (int c = 0; c < 2; ++c) {
+        if (cref[c] & RT_LEAF_BIT) {
+            for (int x = 0; x < 3; ++x) box[n][x] = cbox[c][x];
+            ref[n++] = cref[c];
+        } else {
+            const uint4 ga = qnodes[cref[c] * 2], gb = qnodes[cref[c] * 2 + 1];
+            box[n][0] = ga.x; box[n][1] = ga.y; box[n][2] = ga.z;
+            ref[n++] = gb.z;
+            box[n][0] = ga.w; box[n][1] = gb.x; box[n][2] = gb.y;
+            ref[n++] = gb.w;
+        }
+    }
+    wnodes[i * 4 + 0] = make_uint4(box[0][0], box[0][1], box[0][2], box[1][0]);
+    wnodes[i * 4 + 1] = make_uint4(box[1][1], box[1][2], box[2][0], box[2][1]);
+    wnodes[i * 4 + 2] = make_uint4(box[2][2], box[3][0], box[3][1], box[3][2]);
+    wnodes[i * 4 + 3] = make_uint4(ref[0], ref[1], ref[2], ref[3]);
+}
+
 // ------------------------------------------------------------------ leaf packing
 __global__ __launch_bounds__(256) void k_pack_leaves(uint32_t N, const uint32_t *__restrict__ sortedIdx,
                                                       const uint32_t *__restrict__ idx, const float *__restrict__ verts,
@@ -764,7 +796,7 @@ void rt_free_build(RtContext *ctx)
 {
     void **ptrs[] = {(void **)&ctx->dTriAABB, (void **)&ctx->dMortonUnsorted, (void **)&ctx->dMortonSortedRaw,
                      (void **)&ctx->dMorton, (void **)&ctx->dSortedIdx, (void **)&ctx->dLeft, (void **)&ctx->dRight,
-                     (void **)&ctx->dParent, (void **)&ctx->dLeafParent, (void **)&ctx->dBvhData, (void **)&ctx->dNodes, (void **)&ctx->dQNodes,
+                     (void **)&ctx->dParent, (void **)&ctx->dLeafParent, (void **)&ctx->dBvhData, (void **)&ctx->dNodes, (void **)&ctx->dQNodes, (void **)&ctx->dWNodes,
                      (void **)&ctx->dLeafTri, (void **)&ctx->dLeafShade, (void **)&ctx->dLeafRank};
     for (void **p : ptrs) {
         if (*p) (void)hipFree(*p);
@@ -955,6 +987,7 @@ int rt_build_impl(RtContext *ctx)
     RT_HIP(ctx, dalloc(&ctx->dBvhData, (size_t)NI));
     RT_HIP(ctx, dalloc(&ctx->dNodes, (size_t)NI));
     RT_HIP(ctx, dalloc(&ctx->dQNodes, (size_t)NI));
+    RT_HIP(ctx, dalloc(&ctx->dWNodes, (size_t)NI));
     RT_HIP(ctx, dalloc(&ctx->dLeafTri, (size_t)N));
     RT_HIP(ctx, dalloc(&ctx->dLeafShade, (size_t)N));
     RT_HIP(ctx, dalloc(&ctx->dLeafRank, (size_t)N));
@@ -1013,6 +1046,7 @@ int rt_build_impl(RtContext *ctx)
         rt_timer_begin(ctx, "k_emit_qnodes");
         hipLaunchKernelGGL(k_emit_qnodes, gridNI, blk, 0, st, N, plan, wLeft, wRight, wLeafBox,
                            (const float4 *)wBvhData, (uint4 *)ctx->dQNodes, ctx->dErrorFlag);
+        hipLaunchKernelGGL(k_emit_wide_nodes, gridNI, blk, 0, st, NI, (const uint4 *)ctx->dQNodes, (uint4 *)ctx->dWNodes);
         rt_timer_end(ctx);
         rt_timer_begin(ctx, "k_pack_leaves");
         hipLaunchKernelGGL(k_pack_leaves, gridN, blk, 0, st, N, wSortedIdx, ctx->dIdx, (const float *)ctx->dVerts, ctx->dMatIdx, ctx->dShadow,

@@ -686,6 +686,7 @@ RtSceneView rt_scene_view(RtContext *ctx)
     memset(&sv, 0, sizeof sv);
     sv.nodes = ctx->dNodes;
     sv.qnodes = ctx->dQNodes;
+    sv.wnodes = (ctx->optWideNodes && !ctx->countersOn) ? ctx->dWNodes : nullptr;   // the counting kernels walk what the CPU checker restates
     sv.grid = ctx->grid;
     sv.leafTri = ctx->dLeafTri;
     sv.leafShade = ctx->dLeafShade;

@@ -41,6 +41,16 @@ struct __attribute__((aligned(16))) RtQNode {
 };
 static_assert(sizeof(RtQNode) == 32, "quantised node layout");
 
+// Two levels of that tree in one record, 64 B: the boxes and references of a node's GRANDCHILDREN (of a child that is
+// a leaf: the child itself), up to four; an unused place holds a box no ray passes (low planes above high planes) and
+// RT_INVALID.  The walk through these records visits every other level of the tree: half as many dependent fetches.
+struct __attribute__((aligned(16))) RtQNode4 {
+    uint32_t box[4][3];                   // x, y, z planes of each place: low | high << 16 (binary16, grid of rt_qh.h)
+    uint32_t child[4];                    // index | RT_LEAF_BIT
+};
+static_assert(sizeof(RtQNode4) == 64, "wide node layout");
+#define RT_QH_NO_BOX 0xFBFF7BFFu          // low plane +65504, high plane -65504: near beyond far for every ray
+
 // Intersection record of the triangle at sorted leaf j, 64 B: v0 and the two
 // edge vectors (the same subtractions IntersectTriangle_MT97 performs first)
 // and the triangle's exact padded box (triangleAABB[tri]).
@@ -69,6 +79,7 @@ struct RtHitRec {              // 16 B: result of one BVHRayTrace
 struct RtSceneView {
     const RtNode64 *nodes;
     const RtQNode *qnodes;
+    const RtQNode4 *wnodes;    // the same tree two levels at a time, or nullptr: walk the binary nodes (RT_OPT_WIDE_NODES)
     RtQGrid grid;
     const RtLeafTri *leafTri;
     const RtLeafShade *leafShade;
@@ -230,6 +241,8 @@ struct RtContext {
     RtAABB *dBvhData = nullptr;
     RtNode64 *dNodes = nullptr;
     RtQNode *dQNodes = nullptr;
+    RtQNode4 *dWNodes = nullptr;          // two levels of the traversal tree per record (k_emit_wide_nodes)
+    bool optWideNodes = false;            // RT_OPT_WIDE_NODES
     RtQGrid grid;
     RtLeafTri *dLeafTri = nullptr;
     RtLeafShade *dLeafShade = nullptr;

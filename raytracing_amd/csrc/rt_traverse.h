@@ -444,6 +444,103 @@ __device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySla
     }
 }
 
+// The node phase over the 64-byte records that hold two levels of the tree (RtQNode4): one step fetches the boxes of up
+// to four grandchildren, queues the leaves among them whose box may pass, goes on with the nearest internal one that
+// may pass and stacks the others.  Same stack as node_phase (level 0 holds TRV_DONE, entries are node numbers of the
+// same tree), without the register copy of its top; same end test; same results, because inner nodes are only a filter
+// (a box that is not tested -- the child's, between a node and its grandchildren -- cannot lose a triangle).
+template <uint32_t OCT>
+__device__ __forceinline__ bool wide_box(const RtRaySlab &slab, uint32_t wx, uint32_t wy, uint32_t wz, uint32_t ref, const float limit, float *tnear)
+{
+    const bool maybe = OCT < 8u ? rt_slab_maybe_octant_near<(OCT & 7u)>(slab, wx, wy, wz, tnear) : rt_slab_maybe_near(slab, wx, wy, wz, tnear);
+    return maybe && *tnear <= limit && ref != RT_INVALID;       // (an unused place: its box fails the octant test, but not the one that sorts the planes)
+}
+
+template <uint32_t OCT>
+__device__ __forceinline__ void node_phase_wide(const RtSceneView &sv, const RtRaySlab &slab, WalkState &w, uint32_t *stk, uint32_t *pend,
+                                                uint32_t *spill, const uint32_t spillLanes, const bool feedExhausted, const float limit,
+                                                const uint32_t shareTrips)
+{
+    uint32_t trips = 0;
+    for (;;) {
+        const bool busy = w.node != TRV_DONE, room = w.npend + 4u <= TRV_PEND_CAP;
+        const bool act = busy && room;
+        const unsigned long long busyMask = __ballot(busy);
+        const uint32_t nAct = lane_count(busyMask & __ballot(room));
+        const uint32_t nBusy = lane_count(busyMask);
+        if (nAct == 0u || nAct * TRV_WALK_DEN < nBusy * TRV_WALK_NUM || (!feedExhausted && nBusy < 64u - TRV_REFILL_MIN)) break;
+        if (nBusy <= 64u - TRV_SHARE_MIN_IDLE && ++trips > shareTrips) break;
+        if (act) {
+            const uint4 *np = (const uint4 *)(sv.wnodes + w.node);
+            const uint4 qa = np[0], qb = np[1], qc = np[2], qd = np[3];
+            const uint32_t r0 = qd.x, r1 = qd.y, r2 = qd.z, r3 = qd.w;
+            float n0, n1, n2, n3;
+            const bool h0 = wide_box<OCT>(slab, qa.x, qa.y, qa.z, r0, limit, &n0);
+            const bool h1 = wide_box<OCT>(slab, qa.w, qb.x, qb.y, r1, limit, &n1);
+            const bool h2 = wide_box<OCT>(slab, qb.z, qb.w, qc.x, r2, limit, &n2);
+            const bool h3 = wide_box<OCT>(slab, qc.y, qc.z, qc.w, r3, limit, &n3);
+            const bool l0 = (r0 & RT_LEAF_BIT) != 0, l1 = (r1 & RT_LEAF_BIT) != 0, l2 = (r2 & RT_LEAF_BIT) != 0, l3 = (r3 & RT_LEAF_BIT) != 0;
+            // leaves whose box may pass: every store happens, the count moves on only where it is needed
+            pend[w.npend * TRV_THREADS] = r0 & ~RT_LEAF_BIT;
+            w.npend += (l0 && h0) ? 1u : 0u;
+            pend[w.npend * TRV_THREADS] = r1 & ~RT_LEAF_BIT;
+            w.npend += (l1 && h1) ? 1u : 0u;
+            pend[w.npend * TRV_THREADS] = r2 & ~RT_LEAF_BIT;
+            w.npend += (l2 && h2) ? 1u : 0u;
+            pend[w.npend * TRV_THREADS] = r3 & ~RT_LEAF_BIT;
+            w.npend += (l3 && h3) ? 1u : 0u;
+            // internal nodes to visit: the nearest one next, the others on the stack
+            const bool g0 = !l0 && h0, g1 = !l1 && h1, g2 = !l2 && h2, g3 = !l3 && h3;
+            const float k0 = g0 ? n0 : rt_inf(), k1 = g1 ? n1 : rt_inf(), k2 = g2 ? n2 : rt_inf(), k3 = g3 ? n3 : rt_inf();
+            const bool b01 = k1 < k0, b23 = k3 < k2;
+            const float m01 = b01 ? k1 : k0, m23 = b23 ? k3 : k2;
+            const bool bb = m23 < m01;
+            const uint32_t best = bb ? (b23 ? 3u : 2u) : (b01 ? 1u : 0u);
+            const uint32_t bestRef = bb ? (b23 ? r3 : r2) : (b01 ? r1 : r0);
+            const bool any = g0 || g1 || g2 || g3;
+            const bool p0 = g0 && best != 0u, p1 = g1 && best != 1u, p2 = g2 && best != 2u, p3 = g3 && best != 3u;
+            if (__builtin_expect(w.sp + 3u < TRV_STACK_LDS, 1)) {    // levels sp .. sp + 3 are all LDS levels
+                stk[w.sp * TRV_THREADS] = r0;
+                w.sp += p0 ? 1u : 0u;
+                stk[w.sp * TRV_THREADS] = r1;
+                w.sp += p1 ? 1u : 0u;
+                stk[w.sp * TRV_THREADS] = r2;
+                w.sp += p2 ? 1u : 0u;
+                stk[w.sp * TRV_THREADS] = r3;
+                w.sp += p3 ? 1u : 0u;
+                w.node = bestRef;
+                if (!any) {
+                    w.sp -= 1u;
+                    w.node = stk[w.sp * TRV_THREADS];
+                }
+            } else {                                                 // near the end of the LDS levels: one push at a time, deep levels in HBM
+                const uint32_t refs[4] = {r0, r1, r2, r3};
+                const bool push[4] = {p0, p1, p2, p3};
+                bool overflow = false;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (push[k]) {
+                        if (w.sp < TRV_STACK_LDS) stk[w.sp * TRV_THREADS] = refs[k];
+                        else if (w.sp < RT_STACK_DEPTH) spill[(size_t)(w.sp - TRV_STACK_LDS) * spillLanes] = refs[k];
+                        else overflow = true;
+                        if (!overflow) w.sp++;
+                    }
+                w.node = bestRef;
+                if (!any) {
+                    w.sp -= 1u;
+                    w.node = w.sp < TRV_STACK_LDS ? stk[w.sp * TRV_THREADS] : spill[(size_t)(w.sp - TRV_STACK_LDS) * spillLanes];
+                }
+                if (overflow) {                                      // deeper than the stack: the ray starts over on the stackless walk
+                    w.node = TRV_DONE;
+                    w.sp = 1;
+                    w.tos = TRV_REDO;
+                    w.npend = 0;
+                }
+            }
+        }
+    }
+}
+
 // Persistent traversal of `src.count()` rays by the waves of the launch (*cursor is 0 at launch).
 //   Src: uint32_t count(); void load(uint32_t i, rt_f3 &o, rt_f3 &d); void store(uint32_t i, const RtHitRec &h);
 // lds: TRV_LDS_WORDS words per block; this lane's first TRV_STACK_LDS stack levels are
@@ -597,6 +694,19 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
             const uint32_t oct = uniform ? ((sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u)) : 8u;
             constexpr bool NEAR = true;                              // every kind of ray gains: a hit found sooner, or a closer one
             const float limit = h.t * sv.pruneScale;                 // +inf without a hit, or with the option off
+            if (!COUNT && sv.wnodes != nullptr) {
+                switch (oct) {
+                case 0: node_phase_wide<0>(sv, slab, w, stk, pend, spill, spillLanes, feed.exhausted, limit, shareTrips); break;
+                case 1: node_phase_wide<1>(sv, slab, w, stk, pend, spill, spillLanes, feed.exhausted, limit, shareTrips); break;
+                case 2: node_phase_wide<2>(sv, slab, w, stk, pend, spill, spillLanes, feed.exhausted, limit, shareTrips); break;
+                case 3: node_phase_wide<3>(sv, slab, w, stk, pend, spill, spillLanes, feed.exhausted, limit, shareTrips); break;
+                case 4: node_phase_wide<4>(sv, slab, w, stk, pend, spill, spillLanes, feed.exhausted, limit, shareTrips); break;
+                case 5: node_phase_wide<5>(sv, slab, w, stk, pend, spill, spillLanes, feed.exhausted, limit, shareTrips); break;
+                case 6: node_phase_wide<6>(sv, slab, w, stk, pend, spill, spillLanes, feed.exhausted, limit, shareTrips); break;
+                case 7: node_phase_wide<7>(sv, slab, w, stk, pend, spill, spillLanes, feed.exhausted, limit, shareTrips); break;
+                default: node_phase_wide<8>(sv, slab, w, stk, pend, spill, spillLanes, feed.exhausted, limit, shareTrips); break;
+                }
+            } else
             switch (oct) {
             case 0: node_phase<0, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips TRV_SHARE_STATS_ARG); break;
             case 1: node_phase<1, COUNT, NEAR>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips TRV_SHARE_STATS_ARG); break;

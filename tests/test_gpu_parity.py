@@ -345,15 +345,17 @@ def test_long_walks_shared_between_lanes_do_not_change_a_bit(core, oracle):
                 c.bvh_build()
                 for o, d in rays:
                     want = orc.trace(o, d)
-                    for prune in (1, 0):
+                    for prune, wide in ((1, 0), (0, 0), (1, 1), (0, 1)):
                         c.set_option(wire.OPT_PRUNE_BY_DISTANCE, prune)
+                        c.set_option(wire.OPT_WIDE_NODES, wide)
                         for on in (1, 0):
                             c.set_option(wire.OPT_SHARE_LONG_WALKS, on)
                             got = c.trace_rays(o, d)
                             for k in ("triangle", "t", "u", "v"):
-                                H.assert_bits_equal(got[k], want[k], f"{sc_name}, {lib_name}, {len(o)} rays, sharing {on}, pruning {prune}: {k}")
+                                H.assert_bits_equal(got[k], want[k], f"{sc_name}, {lib_name}, {len(o)} rays, sharing {on}, pruning {prune}, wide nodes {wide}: {k}")
                 c.set_option(wire.OPT_PRUNE_BY_DISTANCE, 1)
                 c.set_option(wire.OPT_SHARE_LONG_WALKS, 1)
+                c.set_option(wire.OPT_WIDE_NODES, 0)
         sc = scenes.car_standin(96, 64, detail=0.05)
         seeds = scenes.frame_seeds(3, seed=5)
         images = []
@@ -361,14 +363,16 @@ def test_long_walks_shared_between_lanes_do_not_change_a_bit(core, oracle):
             c.upload(sc)
             c.bvh_build()
             c.set_params(sc.params)
-            for on in (1, 0):
+            for on, wide in ((1, 0), (0, 0), (1, 1), (0, 1)):
                 c.set_option(wire.OPT_SHARE_LONG_WALKS, on)
+                c.set_option(wire.OPT_WIDE_NODES, wide)
                 for frames in (seeds, seeds[:1]):              # a batch, and one frame in flight
                     c.set_dirty()
                     c.render_frames(frames)
-                    images.append((f"{lib_name}, sharing {on}, {len(frames)} frame(s)", len(frames),
+                    images.append((f"{lib_name}, sharing {on}, wide nodes {wide}, {len(frames)} frame(s)", len(frames),
                                    c.readback(wire.IMAGE_CONVERGED), c.readback(wire.IMAGE_SHADOWMAP)))
             c.set_option(wire.OPT_SHARE_LONG_WALKS, 1)
+            c.set_option(wire.OPT_WIDE_NODES, 0)
         for label, n, conv, sm in images[1:]:
             ref = next(im for im in images if im[1] == n)
             H.assert_bits_equal(conv, ref[2], f"converged image, {label}")
