@@ -242,7 +242,7 @@ struct RtContext {
     RtNode64 *dNodes = nullptr;
     RtQNode *dQNodes = nullptr;
     RtQNode4 *dWNodes = nullptr;          // two levels of the traversal tree per record (k_emit_wide_nodes)
-    bool optWideNodes = false;            // RT_OPT_WIDE_NODES
+    bool optWideNodes = true;             // RT_OPT_WIDE_NODES
     RtQGrid grid;
     RtLeafTri *dLeafTri = nullptr;
     RtLeafShade *dLeafShade = nullptr;

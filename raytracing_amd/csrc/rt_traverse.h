@@ -54,11 +54,11 @@
 #define TRV_STACK_LDS 16        // stack levels kept in LDS; deeper levels spill to HBM (rare)
 #endif
 #ifndef TRV_REFILL_MIN
-#define TRV_REFILL_MIN 24       // refill when at least this many lanes are idle
+#define TRV_REFILL_MIN 40       // refill when at least this many lanes are idle (16 / 24 / 32 / 40 / 48 with two levels per step: 89.0 / 85.1 / 84.9 / 84.1 / 85.9 ms per image)
 #endif
 #ifndef TRV_WALK_NUM
-#define TRV_WALK_NUM 3u         // leave the node phase when fewer than NUM/DEN of the lanes that still
-#define TRV_WALK_DEN 4u         // have nodes to visit can go on (the rest wait for triangle tests)
+#define TRV_WALK_NUM 1u         // leave the node phase when fewer than NUM/DEN of the lanes that still have nodes to visit
+#define TRV_WALK_DEN 2u         // can go on (the rest wait for triangle tests); 3/4, 3/5, 1/2, 2/5, 1/3 with two levels per step: 87.7 / 85.8 / 85.1 / 85.3 / 86.8 ms per image
 #endif
 // Boxes that begin beyond the closest hit a ray holds are not entered (RT_OPT_PRUNE_BY_DISTANCE): "beyond" with this
 // much room, because the distance of a hit (Moller-Trumbore) and the entry distance of a box (slab test) are two
@@ -210,7 +210,7 @@ __device__ __forceinline__ void flush_counters(const RtSceneView &sv, uint32_t r
 #define TRV_CHUNK_MIN 64u
 #endif
 #ifndef TRV_CHUNK_SHARE
-#define TRV_CHUNK_SHARE 4u      // a reservation is at most 1/SHARE of an even share of the rays that are left (2 / 4 / 8 / 32: 110.5 / 110.7 / 113.0 / 133.9 ms per image)
+#define TRV_CHUNK_SHARE 2u      // a reservation is at most 1/SHARE of an even share of the rays that are left (1 / 2 / 4 with two levels per step: 84.0 / 84.3 / 84.9 ms per image, one frame in flight 4.2 / 4.1 / 4.3 ms; 2 / 4 / 8 / 32 before: 110.5 / 110.7 / 113.0 / 133.9)
 #endif
 // The feed's state is the same in every lane of a wave, and says so to the compiler (which then keeps it in scalar
 // registers).
@@ -492,33 +492,38 @@ __device__ __forceinline__ void node_phase_wide(const RtSceneView &sv, const RtR
             // internal nodes to visit: the nearest one next, the others on the stack
             const bool g0 = !l0 && h0, g1 = !l1 && h1, g2 = !l2 && h2, g3 = !l3 && h3;
             const float k0 = g0 ? n0 : rt_inf(), k1 = g1 ? n1 : rt_inf(), k2 = g2 ? n2 : rt_inf(), k3 = g3 ? n3 : rt_inf();
-            const bool b01 = k1 < k0, b23 = k3 < k2;
-            const float m01 = b01 ? k1 : k0, m23 = b23 ? k3 : k2;
-            const bool bb = m23 < m01;
-            const uint32_t best = bb ? (b23 ? 3u : 2u) : (b01 ? 1u : 0u);
-            const uint32_t bestRef = bb ? (b23 ? r3 : r2) : (b01 ? r1 : r0);
+            // all four in the order the ray enters them (a sorting network of five exchanges): the nearest next, the
+            // others stacked farthest first
+            float s0 = k0, s1 = k1, s2 = k2, s3 = k3;
+            uint32_t t0 = r0, t1 = r1, t2 = r2, t3 = r3;
+#define TRV_EXCHANGE(a, b, ra, rb) { const bool x_ = b < a; const float lo_ = x_ ? b : a, hi_ = x_ ? a : b; const uint32_t rl_ = x_ ? rb : ra, rh_ = x_ ? ra : rb; a = lo_; b = hi_; ra = rl_; rb = rh_; }
+            TRV_EXCHANGE(s0, s1, t0, t1)
+            TRV_EXCHANGE(s2, s3, t2, t3)
+            TRV_EXCHANGE(s0, s2, t0, t2)
+            TRV_EXCHANGE(s1, s3, t1, t3)
+            TRV_EXCHANGE(s1, s2, t1, t2)
+#undef TRV_EXCHANGE
             const bool any = g0 || g1 || g2 || g3;
-            const bool p0 = g0 && best != 0u, p1 = g1 && best != 1u, p2 = g2 && best != 2u, p3 = g3 && best != 3u;
-            if (__builtin_expect(w.sp + 3u < TRV_STACK_LDS, 1)) {    // levels sp .. sp + 3 are all LDS levels
-                stk[w.sp * TRV_THREADS] = r0;
+            const uint32_t bestRef = t0;
+            const bool p0 = s3 < rt_inf(), p1 = s2 < rt_inf(), p2 = s1 < rt_inf();
+            if (__builtin_expect(w.sp + 2u < TRV_STACK_LDS, 1)) {    // levels sp .. sp + 2 are all LDS levels
+                stk[w.sp * TRV_THREADS] = t3;
                 w.sp += p0 ? 1u : 0u;
-                stk[w.sp * TRV_THREADS] = r1;
+                stk[w.sp * TRV_THREADS] = t2;
                 w.sp += p1 ? 1u : 0u;
-                stk[w.sp * TRV_THREADS] = r2;
+                stk[w.sp * TRV_THREADS] = t1;
                 w.sp += p2 ? 1u : 0u;
-                stk[w.sp * TRV_THREADS] = r3;
-                w.sp += p3 ? 1u : 0u;
                 w.node = bestRef;
                 if (!any) {
                     w.sp -= 1u;
                     w.node = stk[w.sp * TRV_THREADS];
                 }
             } else {                                                 // near the end of the LDS levels: one push at a time, deep levels in HBM
-                const uint32_t refs[4] = {r0, r1, r2, r3};
-                const bool push[4] = {p0, p1, p2, p3};
+                const uint32_t refs[3] = {t3, t2, t1};
+                const bool push[3] = {p0, p1, p2};
                 bool overflow = false;
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
+                for (int k = 0; k < 3; ++k)
                     if (push[k]) {
                         if (w.sp < TRV_STACK_LDS) stk[w.sp * TRV_THREADS] = refs[k];
                         else if (w.sp < RT_STACK_DEPTH) spill[(size_t)(w.sp - TRV_STACK_LDS) * spillLanes] = refs[k];

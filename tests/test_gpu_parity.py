@@ -355,7 +355,7 @@ def test_long_walks_shared_between_lanes_do_not_change_a_bit(core, oracle):
                                 H.assert_bits_equal(got[k], want[k], f"{sc_name}, {lib_name}, {len(o)} rays, sharing {on}, pruning {prune}, wide nodes {wide}: {k}")
                 c.set_option(wire.OPT_PRUNE_BY_DISTANCE, 1)
                 c.set_option(wire.OPT_SHARE_LONG_WALKS, 1)
-                c.set_option(wire.OPT_WIDE_NODES, 0)
+                c.set_option(wire.OPT_WIDE_NODES, 1)
         sc = scenes.car_standin(96, 64, detail=0.05)
         seeds = scenes.frame_seeds(3, seed=5)
         images = []
@@ -372,7 +372,7 @@ def test_long_walks_shared_between_lanes_do_not_change_a_bit(core, oracle):
                     images.append((f"{lib_name}, sharing {on}, wide nodes {wide}, {len(frames)} frame(s)", len(frames),
                                    c.readback(wire.IMAGE_CONVERGED), c.readback(wire.IMAGE_SHADOWMAP)))
             c.set_option(wire.OPT_SHARE_LONG_WALKS, 1)
-            c.set_option(wire.OPT_WIDE_NODES, 0)
+            c.set_option(wire.OPT_WIDE_NODES, 1)
         for label, n, conv, sm in images[1:]:
             ref = next(im for im in images if im[1] == n)
             H.assert_bits_equal(conv, ref[2], f"converged image, {label}")

@@ -133,10 +133,16 @@ def test_traversal_stress_10m(core, oracle, soup10m):
     every_box = core.trace_rays(o, d)
     ms_every_box = core.stats()["renderMs"]
     core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 1)
-    print(f"\n{n} incoherent rays through 10 M triangles: {ms:.2f} ms, entering every box {ms_every_box:.2f} ms")
+    core.set_option(wire.OPT_WIDE_NODES, 0)                                        # one level of the tree per step
+    core.reset_stats()
+    binary = core.trace_rays(o, d)
+    ms_binary = core.stats()["renderMs"]
+    core.set_option(wire.OPT_WIDE_NODES, 1)
+    print(f"\n{n} incoherent rays through 10 M triangles: {ms:.2f} ms, entering every box {ms_every_box:.2f} ms, one level per step {ms_binary:.2f} ms")
     for k in ("t", "triangle", "u", "v"):
         assert got[k].tobytes() == again[k].tobytes()                              # idempotent
         assert got[k].tobytes() == every_box[k].tobytes(), k                       # boxes beyond the closest hit hold nothing closer
+        assert got[k].tobytes() == binary[k].tobytes(), k                          # two levels per step or one
     hit = got["triangle"] != 0xFFFFFFFF
     assert hit.mean() > 0.5 and np.isinf(got["t"][~hit]).all()
     assert (got["t"][hit] > 0).all() and (got["u"][hit] >= 0).all() and (got["v"][hit] >= 0).all()
@@ -311,6 +317,7 @@ def test_car_1080p_execution_options_do_not_change_a_bit(core):
         core.set_option(wire.OPT_MATERIAL_SORT, fast)
         core.set_option(wire.OPT_PRUNE_BY_DISTANCE, fast)
         core.set_option(wire.OPT_SHARE_LONG_WALKS, fast)
+        core.set_option(wire.OPT_WIDE_NODES, fast)
         core.set_option(wire.OPT_BATCH_FRAMES, 0 if fast else 8)
         core.set_dirty()
         core.render_frames(seeds)
