@@ -191,7 +191,8 @@ def main():
         core.render_frames(seeds)
         gather_frame()
 
-    # ---- count pass (untimed): exact rays / node tests of one step, counters on
+    # ---- count pass (untimed): exact rays / node tests of one step, counters on (the counting kernels walk one level of
+    #      the tree per step, the timed ones two: box-test counts are the binary walk's, see traversal_counts_note)
     core.enable_counters(True)
     core.reset_stats()
     step()
@@ -343,6 +344,9 @@ def main():
             "bvh_build_bytes_per_triangle": {"contract": 436, "reference_tree_and_leaves": 690, "with_traversal_tree_and_rotations": 2600},
             "bvh_build_mtris_per_s": round(sc.n_triangles / max(build_ms, 1e-6) / 1e3, 2),
             "traversal_counts_per_step": total,
+            "traversal_counts_note": "rays, hits and triangle tests are those of the timed walk; internalVisits / leafVisits are counted by the "
+                                     "kernels with counters, which walk the tree one level per step (the walk the CPU checker restates box for "
+                                     "box), where the timed kernels fetch two levels per step and test the grandchildren's boxes only",
             "roofline": roofline,
             "roofline_other_kernel": other,
         }

@@ -448,6 +448,13 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *                          first) and hand their hit back when done.  Same results bit for bit.  Off while counters
  *                          are enabled (a ray that may stop at its first hit would be counted differently from run to
  *                          run).
+ *   RT_OPT_WIDE_NODES      1 (default): the walkers fetch two levels of the traversal tree per step -- a 64-byte record with
+ *                          the boxes of a node's (up to four) grandchildren -- go on with the nearest one the ray may pass
+ *                          and stack the others farthest first: half as many dependent fetches per ray.  Inner boxes only
+ *                          filter (a triangle is tested when its own box passes, which any walk that skips no subtree
+ *                          finds), so the hits are the same bit for bit; 0 = one level per step.  The kernels that count
+ *                          work (rt_enable_counters) always walk one level per step: theirs is the walk the CPU checker
+ *                          restates box for box, so internalVisits / leafVisits describe that walk.
  *   RT_OPT_OVERLAP_AFTER   0..6, default 0: the bounce whose extend launch the overlap starts after (0: as soon as the
  *                          primary hits are known)
  *   RT_OPT_OVERLAP_CUS     compute units the bounce launches keep meanwhile, default 64 (multiples of 32 measured best);

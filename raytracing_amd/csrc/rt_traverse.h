@@ -453,7 +453,9 @@ template <uint32_t OCT>
 __device__ __forceinline__ bool wide_box(const RtRaySlab &slab, uint32_t wx, uint32_t wy, uint32_t wz, uint32_t ref, const float limit, float *tnear)
 {
     const bool maybe = OCT < 8u ? rt_slab_maybe_octant_near<(OCT & 7u)>(slab, wx, wy, wz, tnear) : rt_slab_maybe_near(slab, wx, wy, wz, tnear);
-    return maybe && *tnear <= limit && ref != RT_INVALID;       // (an unused place: its box fails the octant test, but not the one that sorts the planes)
+    // an unused place holds a box whose low planes lie above its high planes: the octant test never passes it, the
+    // test that sorts a slab's two planes would
+    return maybe && *tnear <= limit && (OCT < 8u || ref != RT_INVALID);
 }
 
 template <uint32_t OCT>
@@ -480,14 +482,15 @@ __device__ __forceinline__ void node_phase_wide(const RtSceneView &sv, const RtR
             const bool h2 = wide_box<OCT>(slab, qb.z, qb.w, qc.x, r2, limit, &n2);
             const bool h3 = wide_box<OCT>(slab, qc.y, qc.z, qc.w, r3, limit, &n3);
             const bool l0 = (r0 & RT_LEAF_BIT) != 0, l1 = (r1 & RT_LEAF_BIT) != 0, l2 = (r2 & RT_LEAF_BIT) != 0, l3 = (r3 & RT_LEAF_BIT) != 0;
-            // leaves whose box may pass: every store happens, the count moves on only where it is needed
-            pend[w.npend * TRV_THREADS] = r0 & ~RT_LEAF_BIT;
+            // leaves whose box may pass: every store happens, the count moves on only where it is needed (the reference
+            // goes in as it is, leaf bit and all: the triangle phase takes the bit off)
+            pend[w.npend * TRV_THREADS] = r0;
             w.npend += (l0 && h0) ? 1u : 0u;
-            pend[w.npend * TRV_THREADS] = r1 & ~RT_LEAF_BIT;
+            pend[w.npend * TRV_THREADS] = r1;
             w.npend += (l1 && h1) ? 1u : 0u;
-            pend[w.npend * TRV_THREADS] = r2 & ~RT_LEAF_BIT;
+            pend[w.npend * TRV_THREADS] = r2;
             w.npend += (l2 && h2) ? 1u : 0u;
-            pend[w.npend * TRV_THREADS] = r3 & ~RT_LEAF_BIT;
+            pend[w.npend * TRV_THREADS] = r3;
             w.npend += (l3 && h3) ? 1u : 0u;
             // internal nodes to visit: the nearest one next, the others on the stack
             const bool g0 = !l0 && h0, g1 = !l1 && h1, g2 = !l2 && h2, g3 = !l3 && h3;
@@ -757,8 +760,8 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                 pN[4] += (unsigned long long)__popcll(__ballot(k < npend));
 #endif
                 const bool t0 = k < npend, t1 = k + 1u < npend;
-                const uint32_t leaf0 = t0 ? pend[k * TRV_THREADS] : 0u;
-                const uint32_t leaf1 = t1 ? pend[(k + 1u) * TRV_THREADS] : 0u;
+                const uint32_t leaf0 = t0 ? pend[k * TRV_THREADS] & ~RT_LEAF_BIT : 0u;
+                const uint32_t leaf1 = t1 ? pend[(k + 1u) * TRV_THREADS] & ~RT_LEAF_BIT : 0u;
                 const float4 *p0 = (const float4 *)(sv.leafTri + leaf0), *p1 = (const float4 *)(sv.leafTri + leaf1);
                 const float4 a0 = p0[0], b0 = p0[1], c0 = p0[2];
                 const float4 a1 = p1[0], b1 = p1[1], c1 = p1[2];
