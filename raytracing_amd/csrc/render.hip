@@ -230,7 +230,7 @@ struct ShadowSrcOverlapped : ShadowSrc {};
 // 89, 28 bytes of scratch, none of it touched inside the node or triangle loops.  Seven (72 registers, 12 stack
 // levels in LDS) is far slower: 118.7 ms.
 template <bool COUNT, class Src>
-__global__ __launch_bounds__(TRV_THREADS, 6) void k_traverse(RtSceneView sv, Src src, uint32_t *__restrict__ cursor)
+__global__ __launch_bounds__(TRV_THREADS, TRV_BLOCKS_PER_CU) void k_traverse(RtSceneView sv, Src src, uint32_t *__restrict__ cursor)
 {
     __shared__ uint32_t lds[TRV_LDS_WORDS];
     traverse_rays<COUNT>(sv, src, cursor, lds);
