@@ -67,6 +67,9 @@
 // Long walks are shared out at the end of a launch (RT_OPT_SHARE_LONG_WALKS, traverse_rays): once the launch has no
 // more rays to deal and at least this many lanes of a wave are idle, idle lanes take over stacked subtrees of lanes that
 // are still walking; the node phase then ends after at most TRV_SHARE_TRIPS steps so that the hand-over comes round.
+#ifndef TRV_TRI_MIN_LANES
+#define TRV_TRI_MIN_LANES 8u    // the triangle phase ends when fewer lanes than this still have triangles queued (0 = when none has; 0 / 8 / 16 / 24 / 32: 84.3 / 82.8 / 83.0 / 83.6 / 85.4 ms per image)
+#endif
 #ifndef TRV_SHARE_MIN_IDLE
 #define TRV_SHARE_MIN_IDLE 32u
 #endif
@@ -754,10 +757,18 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
             // several queued triangles pays the memory round trip once per pair (the tests themselves are
             // short; the trip time is the latency of the 48-byte fetch).  Lanes with nothing queued fetch
             // record 0 (one cache line for the whole wave) and skip the test.
-            for (uint32_t k = 0; __ballot(k < npend) != 0ull; k += 2u) {
+            // The phase ends when fewer than TRV_TRI_MIN_LANES lanes still have triangles queued (after one trip at
+            // least): what is left -- the triangles those lanes met last, the farthest ones -- stays queued, moved to the
+            // front of the list, and is tested in the next turn of the main loop together with what the node phase adds;
+            // a ray retires when its walk is over AND its list is empty.  (No result depends on when a queued triangle
+            // is tested.)
+            uint32_t k = 0;
+            for (;; k += 2u) {
+                const uint32_t nLeft = lane_count(__ballot(k < npend));
+                if (nLeft == 0u || (k != 0u && nLeft < TRV_TRI_MIN_LANES)) break;
 #ifdef TRV_PROFILE
                 pN[3]++;
-                pN[4] += (unsigned long long)__popcll(__ballot(k < npend));
+                pN[4] += (unsigned long long)nLeft;
 #endif
                 const bool t0 = k < npend, t1 = k + 1u < npend;
                 const uint32_t leaf0 = t0 ? pend[k * TRV_THREADS] & ~RT_LEAF_BIT : 0u;
@@ -780,11 +791,19 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                     }
                 }
             }
+            // what stays queued moves to the front of its list (few lanes, few entries)
+            const uint32_t left = npend > k ? npend - k : 0u;
+            for (uint32_t m = 0; __ballot(m < left) != 0ull; ++m)
+                if (m < left) pend[m * TRV_THREADS] = pend[(k + m) * TRV_THREADS];
+            w.npend = left;
         }
-        w.npend = 0;
-        if (Src::FIRST_HIT_MAY_DECIDE && hasRay && h.leaf != RT_INVALID && w.node != TRV_DONE && firstHit != 2u) {
+        if (COUNT) w.npend = 0;
+        if (Src::FIRST_HIT_MAY_DECIDE && hasRay && h.leaf != RT_INVALID && (w.node != TRV_DONE || w.npend != 0u) && firstHit != 2u) {
             if (firstHit == 0u) firstHit = src.first_hit_decides(o, d, r) ? 1u : 2u;
-            if (firstHit == 1u) w.node = TRV_DONE;             // retired below
+            if (firstHit == 1u) {                              // retired below
+                w.node = TRV_DONE;
+                w.npend = 0;
+            }
         }
         TRV_PHASE(2)
         TRV_SHARE_CLK(2)
@@ -793,7 +812,7 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
         //      which keeps it if it is closer than its own, or as close and earlier in the reference's order
         if (sharing && feed.exhausted) {
             for (;;) {
-                const unsigned long long fin = __ballot(hasRay && w.node == TRV_DONE && (share & 0x01007F00u) == 0x01000000u);
+                const unsigned long long fin = __ballot(hasRay && w.node == TRV_DONE && w.npend == 0u && (share & 0x01007F00u) == 0x01000000u);
                 if (fin == 0ull) break;
                 const uint32_t T = (uint32_t)__ffsll((long long)fin) - 1u;                 // wave-uniform
                 const uint32_t giver = (lane_value(share, T) >> 16) & 63u;
@@ -814,7 +833,7 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
             }
         }
         // ---- retire finished rays (one that gave subtrees away waits for them)
-        if (hasRay && w.node == TRV_DONE && (share & 0x01007F00u) == 0u) {
+        if (hasRay && w.node == TRV_DONE && w.npend == 0u && (share & 0x01007F00u) == 0u) {
             src.store(rayIdx, h);
             if (COUNT && h.leaf != RT_INVALID) nHits++;
             hasRay = false;
