@@ -533,37 +533,41 @@ __global__ __launch_bounds__(Q_THREADS) void k_sm_setup(RtSceneView sv, RtTileMa
             int castShadow;
             load_hit(sv, h, rt_mk3(r0.x, r0.y, r0.z), rt_mk3(r0.w, r1.x, r1.y), hit, castShadow);
             const rt_f3 origin = rt_add3(hit.position, rt_scale3(hit.normal, RT_NORMAL_BIAS));
-            rt_rng r;
-            uint32_t px, py;
-            uint32_t frameOfSlot;
-            tm.slot_to_pixel(tm.local_slot(slot, &frameOfSlot), &px, &py);
-            const uint2 rs = rng[slot];
-            r.state = rs.x;
-            r.seed = __uint_as_float(rs.y);
-            r.px = (float)px;
-            r.py = (float)py;
-            const float blueNoise = rt_rand(&r);
-            const float theta = blueNoise * 2.0f * RT_PI;
-            const float cosTheta = rt_cos(theta);
-            const float sinTheta = rt_sin(theta);
             const float alpha = hit.materialType == 4 ? 0.0f : 1.0f;
-            rec[slot * 2 + 0] = make_float4(origin.x, origin.y, origin.z, cosTheta);
-            rec[slot * 2 + 1] = make_float4(sinTheta, alpha, 0.0f, 0.0f);
-            shaded = true;
-            if (skipUnshadowable) {
-                // a pixel none of whose 16 rays can meet a shadow caster is lit: what k_sm_resolve makes of 16 misses
-                bool any = false;
-                if (!frame.cone_misses_the_casters(origin)) {
+            // a pixel none of whose 16 rays can meet a shadow caster is lit: what k_sm_resolve makes of 16 misses.  The
+            // cone test needs the origin only, so it comes before the pixel's random angle is drawn (the draw is local
+            // to this kernel: nothing else sees whether it was made)
+            bool any = !(skipUnshadowable && frame.cone_misses_the_casters(origin));
+            if (any) {
+                rt_rng r;
+                uint32_t px, py;
+                uint32_t frameOfSlot;
+                tm.slot_to_pixel(tm.local_slot(slot, &frameOfSlot), &px, &py);
+                const uint2 rs = rng[slot];
+                r.state = rs.x;
+                r.seed = __uint_as_float(rs.y);
+                r.px = (float)px;
+                r.py = (float)py;
+                const float blueNoise = rt_rand(&r);
+                const float theta = blueNoise * 2.0f * RT_PI;
+                const float cosTheta = rt_cos(theta);
+                const float sinTheta = rt_sin(theta);
+                if (skipUnshadowable) {
+                    any = false;
 #pragma unroll 1
                     for (uint32_t k = 0; k < 16u && !any; ++k) any = frame.may_meet_a_caster(origin, frame.direction(k, cosTheta, sinTheta));
                 }
-                if (!any) {
-                    const rt_f3 lit = rt_lerp3(rt_splat3(1.0f), rt_mk3(P.shadowParameter[0], P.shadowParameter[1], P.shadowParameter[2]),
-                                               P.shadowParameter[3] * 0.0f);
-                    shadowMap[slot] = make_float4(lit.x, lit.y, lit.z, alpha);
-                    shaded = false;
-                    skipped = true;
+                if (any) {
+                    rec[slot * 2 + 0] = make_float4(origin.x, origin.y, origin.z, cosTheta);
+                    rec[slot * 2 + 1] = make_float4(sinTheta, alpha, 0.0f, 0.0f);
+                    shaded = true;
                 }
+            }
+            if (!any) {
+                const rt_f3 lit = rt_lerp3(rt_splat3(1.0f), rt_mk3(P.shadowParameter[0], P.shadowParameter[1], P.shadowParameter[2]),
+                                           P.shadowParameter[3] * 0.0f);
+                shadowMap[slot] = make_float4(lit.x, lit.y, lit.z, alpha);
+                skipped = true;
             }
         }
     }
