@@ -169,9 +169,9 @@ struct ShadowFrame {
 };
 
 struct ShadowSrc {
-    const uint32_t *smq, *smqCount;
-    const float4 *rec;         // per slot: (origin.xyz, cosTheta), (sinTheta, ., ., .)
-    uint8_t *flags;            // per slot x 16
+    const uint32_t *smqCount;
+    const float4 *rec;         // per shaded pixel, in queue order: (origin.xyz, cosTheta), (sinTheta, alpha, path slot, .)
+    uint8_t *flags;            // per shaded pixel x 16, in queue order: a ray's flag is flags[ray index]
     const RtLeafShade *leafShade;
     ShadowFrame frame;
     // All a shadow ray reports is whether its closest hit casts a shadow.  A ray that no NON-casting triangle
@@ -203,8 +203,8 @@ struct ShadowSrc {
     __device__ __forceinline__ uint32_t count() const { return *smqCount * 16u; }
     __device__ __forceinline__ void load(uint32_t i, rt_f3 &o, rt_f3 &d) const
     {
-        const uint32_t slot = smq[i >> 4], k = i & 15u;
-        const float4 a = rec[slot * 2], b = rec[slot * 2 + 1];
+        const uint32_t at = i >> 4, k = i & 15u;                  // the pixel's place in the queue: no look-up on the way to the record
+        const float4 a = rec[(size_t)at * 2], b = rec[(size_t)at * 2 + 1];
         o = rt_mk3(a.x, a.y, a.z);
         d = frame.direction(k, a.w, b.x);
     }
@@ -212,10 +212,9 @@ struct ShadowSrc {
     //  other pixels when it is fetched cost more than the few walks it saved.)
     __device__ __forceinline__ void store(uint32_t i, const RtHitRec &h) const
     {
-        const uint32_t slot = smq[i >> 4], k = i & 15u;
         uint8_t f = 0;
         if (h.leaf != RT_INVALID) f = __float_as_int(((const float4 *)(leafShade + h.leaf))[2].z) > 0 ? 1 : 0;
-        flags[(size_t)slot * 16 + k] = f;
+        flags[i] = f;
     }
 };
 
@@ -509,7 +508,7 @@ __global__ __launch_bounds__(Q_THREADS) void k_shade(RtSceneView sv, RtBruteView
 // rotation) -> traverse 16 shadow rays per shaded pixel -> resolve.
 __global__ __launch_bounds__(Q_THREADS) void k_sm_setup(RtSceneView sv, RtTileMap tm, RtParams P, const float4 *__restrict__ ray,
                                                    const uint32_t *__restrict__ qcount, const uint2 *__restrict__ rng,
-                                                   const RtHitRec *__restrict__ hitRec, float4 *__restrict__ rec,
+                                                   const RtHitRec *__restrict__ hitRec, float4 *__restrict__ rec, float4 *__restrict__ recQ,
                                                    float4 *__restrict__ shadowMap, uint32_t *__restrict__ smq,
                                                    uint32_t *__restrict__ smqCount, ShadowFrame frame, int skipUnshadowable,
                                                    unsigned long long *__restrict__ shadowRayCounter)
@@ -577,7 +576,14 @@ __global__ __launch_bounds__(Q_THREADS) void k_sm_setup(RtSceneView sv, RtTileMa
         if ((threadIdx.x & 63u) == 0 && m) atomicAdd(shadowRayCounter, 16ull * (unsigned long long)__popcll(m));
     }
     }
-    block_queue_flush(stage, smqCount, [&](uint32_t shadedSlot, uint32_t at) { smq[at] = shadedSlot; });
+    // the record of a shaded pixel goes to its place in the queue (the thread that made it is the one that places it), with
+    // the path slot in a spare word: the shadow rays and k_sm_resolve read records and flags in queue order
+    block_queue_flush(stage, smqCount, [&](uint32_t shadedSlot, uint32_t at) {
+        smq[at] = shadedSlot;
+        const float4 b = rec[(size_t)shadedSlot * 2 + 1];
+        recQ[(size_t)at * 2] = rec[(size_t)shadedSlot * 2];
+        recQ[(size_t)at * 2 + 1] = make_float4(b.x, b.y, __uint_as_float(shadedSlot), 0.0f);
+    });
 }
 
 // SoftShadow's running mean over the 16 rays, in ray order (Shadow.cginc:109-112).
@@ -588,7 +594,7 @@ __global__ __launch_bounds__(256) void k_sm_resolve(RtParams P, const uint32_t *
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= *smqCount) return;
     const uint32_t slot = smq[i];
-    const uint4 f4 = *(const uint4 *)(flags + (size_t)slot * 16);
+    const uint4 f4 = *(const uint4 *)(flags + (size_t)i * 16);
     const uint32_t w[4] = {f4.x, f4.y, f4.z, f4.w};
     float shadowTerm = 0.0f;
 #pragma unroll
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(256) void k_sm_resolve(RtParams P, const uint32_t *
         if ((w[k >> 2] >> ((k & 3) * 8)) & 0xFFu) shadowTerm = rt_lerp(shadowTerm, 1.0f, 1.0f / (float)(k + 1));
     const rt_f3 s = rt_lerp3(rt_splat3(1.0f), rt_mk3(P.shadowParameter[0], P.shadowParameter[1], P.shadowParameter[2]),
                              P.shadowParameter[3] * shadowTerm);
-    shadowMap[slot] = make_float4(s.x, s.y, s.z, rec[slot * 2 + 1].y);
+    shadowMap[slot] = make_float4(s.x, s.y, s.z, rec[(size_t)i * 2 + 1].y);
 }
 
 // ------------------------------------------------------------------ accumulate
@@ -737,7 +743,7 @@ void rt_free_render(RtContext *ctx)
 {
     void **ptrs[] = {(void **)&ctx->dRt, (void **)&ctx->dConv, (void **)&ctx->dShadowMap,
                      (void **)&ctx->dPe, (void **)&ctx->dRng, (void **)&ctx->dHit,
-                     (void **)&ctx->dRay[0], (void **)&ctx->dRay[1], (void **)&ctx->dSmQueue, (void **)&ctx->dSmRec,
+                     (void **)&ctx->dRay[0], (void **)&ctx->dRay[1], (void **)&ctx->dSmQueue, (void **)&ctx->dSmRec, (void **)&ctx->dSmRecQ,
                      (void **)&ctx->dSmFlags, (void **)&ctx->dSeeds};
     for (void **p : ptrs) {
         if (*p) (void)hipFree(*p);
@@ -755,7 +761,7 @@ static int alloc_batch(RtContext *ctx, uint32_t frames)
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     void **ptrs[] = {(void **)&ctx->dRt, (void **)&ctx->dShadowMap, (void **)&ctx->dPe,
                      (void **)&ctx->dRng, (void **)&ctx->dHit, (void **)&ctx->dRay[0], (void **)&ctx->dRay[1],
-                     (void **)&ctx->dSmQueue, (void **)&ctx->dSmRec, (void **)&ctx->dSmFlags, (void **)&ctx->dSeeds};
+                     (void **)&ctx->dSmQueue, (void **)&ctx->dSmRec, (void **)&ctx->dSmRecQ, (void **)&ctx->dSmFlags, (void **)&ctx->dSeeds};
     for (void **p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -771,6 +777,7 @@ static int alloc_batch(RtContext *ctx, uint32_t frames)
     RT_HIP(ctx, hipMalloc((void **)&ctx->dRay[1], m * 2 * sizeof(float4)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dSmQueue, m * sizeof(uint32_t)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dSmRec, m * 2 * sizeof(float4)));
+    RT_HIP(ctx, hipMalloc((void **)&ctx->dSmRecQ, m * 2 * sizeof(float4)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dSmFlags, m * 16));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dSeeds, RT_MAX_BATCH * sizeof(float)));
     RT_HIP(ctx, hipMemsetAsync(ctx->dRt, 0, m * sizeof(float4), ctx->stream));
@@ -864,7 +871,7 @@ static void launch_sm_setup(RtContext *ctx, const RtSceneView &sv, uint32_t tota
 {
     rt_timer_begin(ctx, "k_sm_setup");
     hipLaunchKernelGGL(k_sm_setup, dim3((total + Q_TILE - 1) / Q_TILE), dim3(Q_THREADS), 0, ctx->stream, sv, ctx->tile, ctx->params, ray, qcount,
-                       ctx->dRng, ctx->dHit, ctx->dSmRec, ctx->dShadowMap, ctx->dSmQueue, ctx->dQCount + CNT_SMQ,
+                       ctx->dRng, ctx->dHit, ctx->dSmRec, ctx->dSmRecQ, ctx->dShadowMap, ctx->dSmQueue, ctx->dQCount + CNT_SMQ,
                        shadow_frame(ctx), ctx->optCasterBox ? 1 : 0, ctx->countersOn ? ctx->dStats + 37 : nullptr);
     rt_timer_end(ctx);
 }
@@ -897,9 +904,8 @@ static ShadowFrame shadow_frame(RtContext *ctx)
 static ShadowSrc shadow_source(RtContext *ctx)
 {
     ShadowSrc sh;
-    sh.smq = ctx->dSmQueue;
     sh.smqCount = ctx->dQCount + CNT_SMQ;
-    sh.rec = ctx->dSmRec;
+    sh.rec = ctx->dSmRecQ;
     sh.flags = ctx->dSmFlags;
     sh.leafShade = ctx->dLeafShade;
     sh.frame = shadow_frame(ctx);
@@ -916,7 +922,7 @@ static void launch_sm_resolve(RtContext *ctx, uint32_t total)
 {
     rt_timer_begin(ctx, "k_sm_resolve");
     hipLaunchKernelGGL(k_sm_resolve, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, ctx->params, ctx->dSmQueue, ctx->dQCount + CNT_SMQ,
-                       ctx->dSmRec, ctx->dSmFlags, ctx->dShadowMap);
+                       ctx->dSmRecQ, ctx->dSmFlags, ctx->dShadowMap);
     rt_timer_end(ctx);
 }
 
@@ -1231,20 +1237,20 @@ int rt_accumulate_impl(RtContext *ctx, uint32_t samplePerPixel, int useShadowMap
 struct RtLaneScope {
     RtContext *ctx;
     hipStream_t stream;
-    float4 *rt, *sm, *pe, *smRec, *ray0, *ray1;
+    float4 *rt, *sm, *pe, *smRec, *smRecQ, *ray0, *ray1;
     uint2 *rng;
     RtHitRec *hit;
     uint32_t *smq, *cnt;
     uint8_t *smFlags;
     float *seeds;
     RtLaneScope(RtContext *c, hipStream_t s, uint32_t firstFrame, uint32_t *counters)
-        : ctx(c), stream(c->stream), rt(c->dRt), sm(c->dShadowMap), pe(c->dPe), smRec(c->dSmRec), ray0(c->dRay[0]), ray1(c->dRay[1]), rng(c->dRng),
+        : ctx(c), stream(c->stream), rt(c->dRt), sm(c->dShadowMap), pe(c->dPe), smRec(c->dSmRec), smRecQ(c->dSmRecQ), ray0(c->dRay[0]), ray1(c->dRay[1]), rng(c->dRng),
           hit(c->dHit), smq(c->dSmQueue), cnt(c->dQCount), smFlags(c->dSmFlags), seeds(c->dSeeds)
     {
         const size_t off = (size_t)firstFrame * c->tile.nSlots;
         c->stream = s;
         c->dRt += off; c->dShadowMap += off; c->dPe += off; c->dRng += off; c->dHit += off;
-        c->dRay[0] += 2 * off; c->dRay[1] += 2 * off; c->dSmQueue += off; c->dSmRec += 2 * off; c->dSmFlags += 16 * off;
+        c->dRay[0] += 2 * off; c->dRay[1] += 2 * off; c->dSmQueue += off; c->dSmRec += 2 * off; c->dSmRecQ += 2 * off; c->dSmFlags += 16 * off;
         c->dSeeds += firstFrame;
         c->dQCount = counters;
         c->spillArea = 1;        // the overlapped shadow launch, the other user of area 1, is off with two streams
@@ -1253,7 +1259,7 @@ struct RtLaneScope {
     {
         RtContext *c = ctx;
         c->stream = stream;
-        c->dRt = rt; c->dShadowMap = sm; c->dPe = pe; c->dSmRec = smRec; c->dRng = rng; c->dHit = hit;
+        c->dRt = rt; c->dShadowMap = sm; c->dPe = pe; c->dSmRec = smRec; c->dSmRecQ = smRecQ; c->dRng = rng; c->dHit = hit;
         c->dRay[0] = ray0; c->dRay[1] = ray1; c->dSmQueue = smq; c->dQCount = cnt; c->dSmFlags = smFlags; c->dSeeds = seeds;
         c->spillArea = 0;
     }

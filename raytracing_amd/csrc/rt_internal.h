@@ -282,6 +282,7 @@ struct RtContext {
     uint32_t batchCap = 0;                // frames the path-state buffers can hold
     uint32_t lastFrame = 0;               // frame of the batch that RT_IMAGE_RT / RT_IMAGE_SHADOWMAP show
     float4 *dSmRec = nullptr;             // ShadowMap pass: 2 x float4 per slot
+    float4 *dSmRecQ = nullptr;            // the same records in the order of the queue of shaded pixels (what the shadow rays read)
     uint8_t *dSmFlags = nullptr;          // ShadowMap pass: 16 results per slot
     int numCU = 256;
     uint32_t sampleCount = 0;
