@@ -402,7 +402,7 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *   RT_OPT_TWO_STREAMS     0 (default): 1 = the frames in flight go down two HIP streams, half each
  *                          (measured 3 % slower: the walkers already fill the chip)
  *   RT_OPT_BATCH_FRAMES    1..64 frames rt_render_frames keeps in flight; 0 (default): as many as give
- *                          up to 128 M paths per launch (64 for a whole 1080p frame, 16 for a 4K frame; 188 bytes of
+ *                          up to 128 M paths per launch (64 for a whole 1080p frame, 16 for a 4K frame; 220 bytes of
  *                          device memory per path, halved until it fits)
  *   RT_OPT_FIRST_HIT_SHADOW 1 (default): a ShadowMap ray only reports whether its closest hit casts a shadow, so a ray
  *                          that stays clear of the box round the scene's non-casting triangles (it can only meet casters)

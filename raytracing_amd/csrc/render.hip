@@ -737,7 +737,7 @@ RtSceneView rt_scene_view(RtContext *ctx)
 #define CNT_WORDS (24 * CNT_LINE)
 static_assert(2 * CNT_WORDS <= RT_COUNTER_BLOCK_WORDS, "counter block too small");   // one per stream
 #define RT_MAX_BATCH 64u
-#define RT_BATCH_PATH_SLOTS (1u << 27)   // frames in flight are chosen so that a launch covers up to this many paths (188 B each: 25 GB)
+#define RT_BATCH_PATH_SLOTS (1u << 27)   // frames in flight are chosen so that a launch covers up to this many paths (220 B each: 29 GB)
 
 void rt_free_render(RtContext *ctx)
 {
