@@ -7,12 +7,11 @@ per pixel.  One STEP = one finished 64-spp image = 64 x { CSMain dispatch,
 ShadowMap dispatch, accumulate } = 64 calls of the reference's CustomRender
 (Assets/Scripts/RayTracing/RayTracing.cs:118-164), followed by gathering the
 accumulated tiles on rank 0.  value = Mrays/s over the whole job, counting RAYS
-ANSWERED: every BVHRayTrace call (camera, bounce or shadow segment) the reference
-makes for the same frames.  Some of them the library settles without a walk (the
-16 soft-shadow rays of a ShadowMap pixel none of whose rays can meet a shadow
-caster); "rays_walked" are the rays a traversal kernel actually took through the
-tree, and "value_rays_walked" is the same rate counted on those alone.  The CPU
-leg counts the same way (it walks every ray it answers).
+WALKED: the BVHRayTrace calls (camera, bounce or shadow segment) a traversal
+kernel took through the tree.  The reference makes more calls for the same frames
+("rays_answered_per_step"; the rate counted on them is "value_rays_answered"):
+the 16 soft-shadow rays of a ShadowMap pixel none of whose rays can meet a shadow
+caster are settled without a walk.  The CPU leg walks every ray it answers.
 
 For N > 1 the fixed frame is cut into 64x64 tiles dealt round-robin to the ranks
 (strong scaling); the scene is broadcast once with RCCL before the timed region
@@ -191,8 +190,8 @@ def main():
         core.render_frames(seeds)
         gather_frame()
 
-    # ---- count pass (untimed): exact rays / node tests of one step, counters on (the counting kernels walk one level of
-    #      the tree per step, the timed ones two: box-test counts are the binary walk's, see traversal_counts_note)
+    # ---- count pass (untimed): exact rays / box tests / triangle tests of one step, counters on: the same walk as the
+    #      timed one (two levels of the tree per step, the same boxes left out), in launches of the plain order
     core.enable_counters(True)
     core.reset_stats()
     step()
@@ -265,7 +264,7 @@ def main():
                      f"{sc.n_triangles} triangles, MIS + DoF + ShadowMap pass")
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = rays_answered * args.steps / elapsed / 1e6
+        value = rays_walked * args.steps / elapsed / 1e6
         # The traversal kernel has two instantiations in a step: k_traverse<QueueSrc> (camera and bounce
         # rays, timed as "k_extend") and k_traverse<ShadowSrc> (16 shadow rays per pixel, "k_shadow_rays").
         # The roofline is quoted for whichever took more device time; the other one is reported beside it.
@@ -329,9 +328,11 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_name,
                        "parallelism": f"image tiles 64x64 round-robin over {world} GPU(s)"},
-            "value_counts": "rays_answered (every BVHRayTrace call the reference makes for these frames)",
-            "rays_answered_per_step": rays_answered, "rays_walked_per_step": rays_walked,
-            "value_rays_walked": round(rays_walked * args.steps / elapsed / 1e6, 3),
+            "value_counts": "rays walked: the BVHRayTrace calls a traversal kernel took through the tree.  The reference makes more "
+                            "calls for the same frames (rays_answered_per_step): the library answers the 16 soft-shadow rays of a "
+                            "ShadowMap pixel that no shadow caster can reach without a walk",
+            "rays_walked_per_step": rays_walked, "rays_answered_per_step": rays_answered,
+            "value_rays_answered": round(rays_answered * args.steps / elapsed / 1e6, 3),
             "ms_per_frame_1spp": round(ms_per_step / args.spp, 4),
             "ms_per_image": round(ms_per_step, 3),
             "per_frame_dropin": None if dropin_ms is None else {
@@ -344,9 +345,6 @@ def main():
             "bvh_build_bytes_per_triangle": {"contract": 436, "reference_tree_and_leaves": 690, "with_traversal_tree_and_rotations": 2600},
             "bvh_build_mtris_per_s": round(sc.n_triangles / max(build_ms, 1e-6) / 1e3, 2),
             "traversal_counts_per_step": total,
-            "traversal_counts_note": "rays, hits and triangle tests are those of the timed walk; internalVisits / leafVisits are counted by the "
-                                     "kernels with counters, which walk the tree one level per step (the walk the CPU checker restates box for "
-                                     "box), where the timed kernels fetch two levels per step and test the grandchildren's boxes only",
             "roofline": roofline,
             "roofline_other_kernel": other,
         }

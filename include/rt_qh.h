@@ -227,6 +227,27 @@ RT_HD bool rt_slab_maybe_octant(const RtRaySlab &s, uint32_t wx, uint32_t wy, ui
 }
 #endif
 
+/* The box an unused place of a two-level record holds: low plane +65504, high plane -65504 on every axis.  Where
+ * near and far planes are picked by the sign of A, the ray's near value on an axis is then
+ * fma(+-65504, A, B -+ M) = 65504 |A| + (B - M) or its mirror image and the far value 65504 |A| less on the other
+ * side, so near > far -- a sure miss -- exactly when 65504 |A| outweighs the margin M on that axis. */
+#define RT_QH_NO_BOX 0xFBFF7BFFu
+
+/* Does the octant test (rt_slab_maybe_octant_near) turn the empty box down for this ray?  Evaluated with that
+ * test's own multiply-adds: it rejects a box as soon as one axis has near > far.  It does for every ray whose
+ * origin is within about a million scene extents of the scene; a ray for which it does not (M outweighs the grid
+ * on all three axes) walks the exact nodes instead, so an unused place is never opened. */
+RT_HD bool rt_slab_rejects_empty_box(const RtRaySlab &s)
+{
+    bool rejects = false;
+    for (int a = 0; a < 3; ++a) {
+        const float lo = __builtin_fmaf(RT_QH_MAX_VALUE, s.A[a], s.Blo[a]), hi = __builtin_fmaf(-RT_QH_MAX_VALUE, s.A[a], s.Bhi[a]);
+        const float tnear = s.A[a] < 0.0f ? hi : lo, tfar = s.A[a] < 0.0f ? lo : hi;
+        rejects = rejects || tnear > tfar;
+    }
+    return rejects;
+}
+
 /* Rays for which "a triangle's box passes => every enclosing box passes" is not
  * guaranteed by monotonicity of IEEE subtraction and division: a zero, infinite
  * or NaN direction component, or a non-finite origin.  Such rays are walked with

@@ -244,8 +244,8 @@ int rt_readback_sort_stages(RtContext *ctx, uint32_t *morton_unsorted, uint32_t 
  * the same steps from finer keys (include/rt_finekey.h); results are the reference's, bit
  * for bit, because (a) which triangles a ray tests depends only on the triangles' own
  * boxes and (b) equally distant triangles are ranked by the reference's visiting order.
- * For checks of that build: internal nodes as 8 words each (six 16-bit grid coordinates
- * per child box in 3 words: left box, right box, then left and right child = index, or
+ * For checks of that build: internal nodes as 8 words each (six half-float (binary16) plane
+ * numbers per child box in 3 words: left box, right box, then left and right child = index, or
  * leaf number | 0x80000000), N-1 of them; per leaf the original triangle index and its
  * place in the reference's visiting order (N each).  Any pointer may be NULL. */
 int rt_readback_walk_tree(RtContext *ctx, uint32_t *nodes8, uint32_t *leaf_triangle, uint32_t *leaf_rank);
@@ -391,8 +391,8 @@ int rt_post_bloom(RtContext *ctx, int src, const RtBloomParams *params);
 int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
 
 /* ------------------------------------------------------------------ tuning */
-/* Execution knobs; none changes a result bit.  No reference counterpart (the
- * reference has one fixed schedule: a thread per pixel, a dispatch per frame).
+/* Execution knobs; none changes a result bit, except RT_OPT_PRUNE_BY_DISTANCE as said there.  No reference
+ * counterpart (the reference has one fixed schedule: a thread per pixel, a dispatch per frame).
  *   RT_OPT_PACKET_SHADOW   0 (default): 1 = the 16 soft-shadow rays of a pixel walk the tree as one packet
  *   RT_OPT_PACKET_PRIMARY  0 (default): 1 = camera rays walk the tree in packets of 16 neighbouring pixels
  *   RT_OPT_PACKET_TRACE    0 (default): 1 = rt_trace_rays walks caller rays 16 at a time
@@ -429,17 +429,26 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *                          rt_dispatch_shadowmap traces its own primary rays as it does with the option off or while
  *                          counters are enabled (the work counters keep the two kernels apart).  Between the two calls
  *                          RT_IMAGE_SHADOWMAP is half written: read it after rt_dispatch_shadowmap, as the reference does.
- *   RT_OPT_PRUNE_BY_DISTANCE 1 (default): a ray does not enter a box that begins more than 1/64 beyond the closest hit it
- *                          holds.  The reference enters every box the ray passes (BVHRayTracing.cginc:87-123 has no
- *                          distance test) and keeps the closest hit; a triangle in a box left out lies behind the hit
- *                          already held, so the hit returned is the same -- up to this: a hit's distance and a box's
- *                          entry distance are separate float computations, and Moller-Trumbore's distance has a relative
- *                          error of about 5e-7 / (angle between ray and triangle plane x sine of the angle between the
- *                          triangle's edges): it exceeds the 1/64 of room for a ray within 3e-5 rad of the plane of a
- *                          well-shaped triangle it hits, within 3e-3 rad for a sliver with edges 0.6 degrees apart.
- *                          No such ray turned up in any test (the full-size frames are bit-identical on and off);
- *                          0 = the reference's walk, box for box (the one whose work counters, rt_enable_counters,
- *                          equal the CPU checker's).
+ *   RT_OPT_PRUNE_BY_DISTANCE  THE ONE KNOB THAT CAN CHANGE A RESULT.  A ray that uses the rule does not enter a box that begins
+ *                          more than 1/64 beyond the closest hit it holds.  The reference enters every box the ray passes
+ *                          (BVHRayTracing.cginc:87-123 has no distance test) and keeps the hit with the smallest COMPUTED
+ *                          distance.  A triangle in a box left out lies behind the hit already held, so the hit returned is the
+ *                          same -- as far as Moller-Trumbore's distance of that triangle is not far in front of the
+ *                          triangle's own box.  Float32 does not promise that for a ray nearly inside the triangle's plane:
+ *                          distance, u and v are all divided by det = e1 . (d x e2), the small difference of large products,
+ *                          whose relative error is about 6e-8 / (angle between ray and plane x sine of the angle between the
+ *                          edges): beyond the 1/64 of room within 4e-6 rad of a well-shaped triangle, within 4e-4 rad of a
+ *                          sliver with edges 0.6 degrees apart, and no wider margin is safe for every triangle.  The CPU
+ *                          checker's model of the rule loses 13 hits in a million on a scene built for it
+ *                          (tests/adversarial.py, tests/test_oracle_cpu.py); on every scene of ordinary shapes, and on that
+ *                          one through the kernels, all values give the same bits (tests/test_gpu_prune.py).  Values:
+ *                            0  no ray uses the rule: the reference's walk, box for box
+ *                            1  (default) the rays whose hits reach the caller only as radiance use it -- the bounce rays of
+ *                               CSMain from the second segment on, the 16 soft-shadow rays of a ShadowMap pixel; the rays
+ *                               whose first hits are handed out triangle by triangle do not: rt_trace_rays*, camera rays
+ *                               (CSMain's first segment, the ShadowMap kernel's primary ray).  Their work counters
+ *                               (rt_enable_counters) equal the CPU checker's
+ *                            2  every ray uses it (the 10 M-triangle stress launch: 31 instead of 106 ms)
  *   RT_OPT_SHARE_LONG_WALKS 1 (default): a walker launch lasts as long as its longest ray, a chain of dependent fetches
  *                          that can run to thousands of steps.  Once a launch has no rays left to deal, lanes of a wave
  *                          that have run out of rays take over stacked subtrees of the lanes that are still walking
@@ -453,8 +462,8 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *                          and stack the others farthest first: half as many dependent fetches per ray.  Inner boxes only
  *                          filter (a triangle is tested when its own box passes, which any walk that skips no subtree
  *                          finds), so the hits are the same bit for bit; 0 = one level per step.  The kernels that count
- *                          work (rt_enable_counters) always walk one level per step: theirs is the walk the CPU checker
- *                          restates box for box, so internalVisits / leafVisits describe that walk.
+ *                          work (rt_enable_counters) walk the same way as the others: internalVisits counts the places of
+ *                          the records fetched that hold a child (two per node visited with one level per step).
  *   RT_OPT_OVERLAP_AFTER   0..6, default 0: the bounce whose extend launch the overlap starts after (0: as soon as the
  *                          primary hits are known)
  *   RT_OPT_OVERLAP_CUS     compute units the bounce launches keep meanwhile, default 64 (multiples of 32 measured best);

@@ -100,9 +100,10 @@ class Oracle:
         out["morton_unsorted"], out["morton_sorted_raw"] = un, raw
         return out
 
-    def trace(self, origins, directions, brute=False, grid=False):
-        """First hits.  brute: loop over all triangles.  grid: the library's grid walk
-        (same hits as the reference's walk, its own box-test counts)."""
+    def trace(self, origins, directions, brute=False, grid=False, wide=False):
+        """First hits.  brute: loop over all triangles.  grid: the library's grid walk, one level of its tree
+        per step; wide: two levels per step, the default walker's (same hits as the reference's walk, their
+        own box-test counts)."""
         o = np.ascontiguousarray(origins, np.float32)
         d = np.ascontiguousarray(directions, np.float32)
         n = len(o)
@@ -111,10 +112,19 @@ class Oracle:
             lib().orc_trace_brute(self.h, _p(o), _p(d), C.c_uint32(n), _p(t), _p(tri))
             return dict(t=t, triangle=tri)
         u, v, cnt = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(5, np.uint64)
-        fn = lib().orc_trace_grid if grid else lib().orc_trace
+        fn = lib().orc_trace_wide if wide else lib().orc_trace_grid if grid else lib().orc_trace
         fn(self.h, _p(o), _p(d), C.c_uint32(n), _p(t), _p(tri), _p(u), _p(v), _p(cnt))
         return dict(t=t, triangle=tri, u=u, v=v,
                     counters=dict(zip(("rays", "internalVisits", "leafVisits", "triTests", "hits"), map(int, cnt))))
+
+    def trace_leaving_out_far_boxes(self, origins, directions, scale):
+        """The grid walk taken front to back WITHOUT entering boxes that begin beyond (closest hit so far) x scale: a
+        model of the library's RT_OPT_PRUNE_BY_DISTANCE rule, for finding the rays whose hit it changes."""
+        lib().orc_set_prune_scale(C.c_float(scale))
+        try:
+            return self.trace(origins, directions, grid=True)
+        finally:
+            lib().orc_set_prune_scale(C.c_float(0.0))
 
     def readback_walk(self):
         """The library's traversal tree as the checker rebuilds it (same wire structs as readback_bvh) and

@@ -655,6 +655,11 @@ const RtAABB &ChildBox(const Scene &s, uint32_t node, uint32_t type)
     return type == RT_INTERNAL_NODE ? s.bvhData[node] : s.triAABB[s.sortedIdx[s.leaves[node].index]];
 }
 
+// Analysis aid (orc_set_prune_scale): while finite, the grid walk goes front to back and does not enter a box whose
+// entry distance exceeds (closest hit so far) x this -- the library's RT_OPT_PRUNE_BY_DISTANCE rule, for finding on
+// the CPU the rays whose hit that rule changes.  +inf (the default): the walk above, every box the ray passes.
+static float g_pruneScale = rt_inf();
+
 void IntersectTriangleGrid(const Scene &ref, const Ray &ray, RayHit &hit, TraceCounters *cnt)
 {
     if (ref.N == 0) return;
@@ -664,7 +669,7 @@ void IntersectTriangleGrid(const Scene &ref, const Ray &ray, RayHit &hit, TraceC
     // tree with the reference's test
     const f3 r = rt_mk3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
     const RtRaySlab slab = rt_ray_slab(ref.grid, ray.origin, r);
-    const bool odd = rt_ray_needs_exact_walk(ray.origin, ray.direction) || !rt_slab_finite(slab);
+    const bool odd = rt_ray_needs_exact_walk(ray.origin, ray.direction) || !rt_slab_finite(slab) || !rt_slab_rejects_empty_box(slab);
     const Scene &s = odd ? ref : *ref.walk;
     uint32_t stack[64];
     uint32_t sp = 0;
@@ -674,21 +679,71 @@ void IntersectTriangleGrid(const Scene &ref, const Ray &ray, RayHit &hit, TraceC
         const RtInternalNode &n = s.inodes[index];
         if (cnt) cnt->internalVisits += 2;
         bool pass[2];
+        float tnear[2] = {0.0f, 0.0f};
         const uint32_t child[2] = {n.leftNode, n.rightNode}, type[2] = {n.leftNodeType, n.rightNodeType};
         for (int c = 0; c < 2; ++c) {
             if (odd) {
                 pass[c] = RayBoxIntersection(ChildBox(s, child[c], type[c]), ray);
             } else {
                 const uint32_t *w = &ref.qboxes[(size_t)index * 6 + c * 3];
-                pass[c] = rt_slab_maybe(slab, w[0], w[1], w[2]);
+                pass[c] = rt_slab_maybe_near(slab, w[0], w[1], w[2], &tnear[c]);
+                if (g_pruneScale < rt_inf() && !(tnear[c] <= hit.distance * g_pruneScale)) pass[c] = false;
             }
         }
         // left leaf, right leaf, then the right subtree before the left one
         for (int c = 0; c < 2; ++c)
             if (type[c] != RT_INTERNAL_NODE && pass[c]) CheckTriangle(ref, s.sortedIdx[s.leaves[child[c]].index], ray, hit, cnt, &ref.visitRank);
-        for (int c = 0; c < 2; ++c)
+        const bool leftFirst = g_pruneScale < rt_inf() && !odd && tnear[0] < tnear[1];   // (the one pushed last is walked first)
+        for (int k = 0; k < 2; ++k) {
+            const int c = leftFirst ? 1 - k : k;
             if (type[c] == RT_INTERNAL_NODE && pass[c]) stack[sp++] = child[c];
+        }
         if (sp > 62) { fprintf(stderr, "oracle: traversal stack overflow\n"); abort(); }
+    }
+}
+
+// The same walk two levels of the tree at a time, as the library's default walker takes it (no reference
+// counterpart): a step looks at a node's GRANDCHILDREN -- of a child that is a leaf, the child itself -- through the
+// boxes their parents hold, so a child's own box is never tested.  Inner boxes only filter, so the hit is the same;
+// what differs is the work: every place of a step that holds a child counts as one box tested.
+void IntersectTriangleWide(const Scene &ref, const Ray &ray, RayHit &hit, TraceCounters *cnt)
+{
+    const f3 r = rt_mk3(1.0f / ray.direction.x, 1.0f / ray.direction.y, 1.0f / ray.direction.z);
+    const RtRaySlab slab = rt_ray_slab(ref.grid, ray.origin, r);
+    if (ref.N < 2 || rt_ray_needs_exact_walk(ray.origin, ray.direction) || !rt_slab_finite(slab) || !rt_slab_rejects_empty_box(slab)) {
+        IntersectTriangleGrid(ref, ray, hit, cnt);       // the exact walk of the reference's tree, as there
+        return;
+    }
+    if (cnt) cnt->internalVisits++;
+    if (!RayBoxIntersection(ref.bvhData[0], ray)) return;
+    const Scene &s = *ref.walk;
+    std::vector<uint32_t> stack{0};
+    while (!stack.empty()) {
+        const uint32_t index = stack.back();
+        stack.pop_back();
+        const RtInternalNode &n = s.inodes[index];
+        const uint32_t child[2] = {n.leftNode, n.rightNode}, type[2] = {n.leftNodeType, n.rightNodeType};
+        for (int c = 0; c < 2; ++c) {
+            // the places this child fills: itself with the box its parent holds, or its two children with the boxes it holds
+            uint32_t place[2], placeType[2];
+            const uint32_t *box[2];
+            int nPlaces = 0;
+            if (type[c] != RT_INTERNAL_NODE) {
+                place[0] = child[c]; placeType[0] = type[c]; box[0] = &ref.qboxes[(size_t)index * 6 + c * 3];
+                nPlaces = 1;
+            } else {
+                const RtInternalNode &g = s.inodes[child[c]];
+                place[0] = g.leftNode; placeType[0] = g.leftNodeType; box[0] = &ref.qboxes[(size_t)child[c] * 6];
+                place[1] = g.rightNode; placeType[1] = g.rightNodeType; box[1] = &ref.qboxes[(size_t)child[c] * 6 + 3];
+                nPlaces = 2;
+            }
+            for (int k = 0; k < nPlaces; ++k) {
+                if (cnt) cnt->internalVisits++;
+                if (!rt_slab_maybe(slab, box[k][0], box[k][1], box[k][2])) continue;
+                if (placeType[k] == RT_INTERNAL_NODE) stack.push_back(place[k]);
+                else CheckTriangle(ref, s.sortedIdx[s.leaves[place[k]].index], ray, hit, cnt, &ref.visitRank);
+            }
+        }
     }
 }
 
@@ -1589,6 +1644,8 @@ void orc_tree_from_codes(const uint32_t *codes, uint32_t n, RtInternalNode *inod
     memcpy(leaves, s.leaves.data(), (size_t)n * sizeof(RtLeafNode));
 }
 
+void orc_set_prune_scale(float scale) { g_pruneScale = scale > 0.0f ? scale : rt_inf(); }
+
 static uint32_t *g_nodeVisits = nullptr;
 // Analysis aid: while set, orc_trace adds 1 to visits[node] for every internal node whose box a ray passes.
 void orc_set_node_visit_histogram(uint32_t *visits) { g_nodeVisits = visits; }
@@ -1628,9 +1685,10 @@ void orc_trace(void *h, const float *o, const float *d, uint32_t n, float *out_t
     }
 }
 
-// The same queries through the grid walk (IntersectTriangleGrid).
-void orc_trace_grid(void *h, const float *o, const float *d, uint32_t n, float *out_t, uint32_t *out_tri,
-                    float *out_u, float *out_v, uint64_t *counters)
+// The same queries through the grid walk (IntersectTriangleGrid) or, wide != 0, the walk that takes two levels of
+// the tree per step (IntersectTriangleWide).
+static void trace_walk(void *h, const float *o, const float *d, uint32_t n, float *out_t, uint32_t *out_tri,
+                       float *out_u, float *out_v, uint64_t *counters, int wide)
 {
     const Scene &s = *(Scene *)h;
     TraceCounters total = {0, 0, 0, 0, 0};
@@ -1642,7 +1700,8 @@ void orc_trace_grid(void *h, const float *o, const float *d, uint32_t n, float *
             Ray r = CreateRay(ld3(o + 3 * i), ld3(d + 3 * i));
             RayHit hit = CreateRayHit();
             c.rays++;
-            IntersectTriangleGrid(s, r, hit, &c);
+            if (wide) IntersectTriangleWide(s, r, hit, &c);
+            else IntersectTriangleGrid(s, r, hit, &c);
             if (hit.distance < rt_inf()) c.hits++;
             if (out_t) out_t[i] = hit.distance;
             if (out_tri) out_tri[i] = hit.triangle;
@@ -1659,6 +1718,17 @@ void orc_trace_grid(void *h, const float *o, const float *d, uint32_t n, float *
         counters[0] = total.rays; counters[1] = total.internalVisits; counters[2] = total.leafVisits;
         counters[3] = total.triTests; counters[4] = total.hits;
     }
+}
+
+void orc_trace_grid(void *h, const float *o, const float *d, uint32_t n, float *out_t, uint32_t *out_tri,
+                    float *out_u, float *out_v, uint64_t *counters)
+{
+    trace_walk(h, o, d, n, out_t, out_tri, out_u, out_v, counters, 0);
+}
+void orc_trace_wide(void *h, const float *o, const float *d, uint32_t n, float *out_t, uint32_t *out_tri,
+                    float *out_u, float *out_v, uint64_t *counters)
+{
+    trace_walk(h, o, d, n, out_t, out_tri, out_u, out_v, counters, 1);
 }
 
 // 1 when every box fitted the grid; grid6 = org[3], step[3]; qboxes = 6 words per internal node (may be NULL).

@@ -610,7 +610,10 @@ int rt_set_option(RtContext *ctx, int option, int value)
     RT_ENTER_CHANGING(ctx);
     switch (option) {
     case RT_OPT_EAGER_SHADOWMAP: ctx->optEagerShadowMap = value != 0; return RT_OK;
-    case RT_OPT_PRUNE_BY_DISTANCE: ctx->optPruneByDistance = value != 0; return RT_OK;
+    case RT_OPT_PRUNE_BY_DISTANCE:
+        if (value < 0 || value > 2) return rt_fail(ctx, RT_E_INVALID, "RT_OPT_PRUNE_BY_DISTANCE must be 0, 1 or 2");
+        ctx->optPruneByDistance = value;
+        return RT_OK;
     case RT_OPT_SHARE_LONG_WALKS: ctx->optShareLongWalks = value != 0; return RT_OK;
     case RT_OPT_WIDE_NODES: ctx->optWideNodes = value != 0; return RT_OK;
     case RT_OPT_PACKET_SHADOW: ctx->optPacketShadow = value != 0; return RT_OK;

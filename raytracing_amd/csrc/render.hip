@@ -690,13 +690,13 @@ int rt_debug_eval_impl(RtContext *ctx, int which, const float *dx, const float *
 }
 
 // ------------------------------------------------------------------ host side
-RtSceneView rt_scene_view(RtContext *ctx)
+RtSceneView rt_scene_view(RtContext *ctx, bool firstHitsHandedOut)
 {
     RtSceneView sv;
     memset(&sv, 0, sizeof sv);
     sv.nodes = ctx->dNodes;
     sv.qnodes = ctx->dQNodes;
-    sv.wnodes = (ctx->optWideNodes && !ctx->countersOn) ? ctx->dWNodes : nullptr;   // the counting kernels walk what the CPU checker restates
+    sv.wnodes = ctx->optWideNodes ? ctx->dWNodes : nullptr;
     sv.grid = ctx->grid;
     sv.leafTri = ctx->dLeafTri;
     sv.leafShade = ctx->dLeafShade;
@@ -715,7 +715,9 @@ RtSceneView rt_scene_view(RtContext *ctx)
     // walker launches that may be on the chip together spill into different areas
     sv.stackSpill = ctx->dStackSpill + (size_t)ctx->spillArea * ctx->numCU * RT_SPILL_WORDS_PER_CU;
     sv.errorFlag = ctx->dErrorFlag;
-    sv.pruneScale = ctx->optPruneByDistance ? RT_PRUNE_SCALE : rt_inf();
+    // Camera rays and caller rays walk every box they pass unless told otherwise: theirs are the hits a caller sees
+    // triangle by triangle, and leaving boxes out can change a hit where Moller-Trumbore's distance is far off (rtcore.h)
+    sv.pruneScale = ctx->optPruneByDistance >= (firstHitsHandedOut ? 2 : 1) ? RT_PRUNE_SCALE : rt_inf();
     sv.shareWalks = ctx->optShareLongWalks ? 1u : 0u;
     return sv;
 }
@@ -1081,7 +1083,7 @@ static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup
     if (n == 0) return RT_OK;
     const uint32_t total = n * frames;
     hipStream_t st = ctx->stream;
-    const RtSceneView sv = rt_scene_view(ctx);
+    const RtSceneView sv = rt_scene_view(ctx), svCamera = rt_scene_view(ctx, true);
     const bool brute = (ctx->params.flags & RT_FLAG_BRUTE_FORCE) != 0;
     const dim3 blk(Q_THREADS), grid((total + Q_TILE - 1) / Q_TILE);
     RT_HIP(ctx, hipMemsetAsync(ctx->dQCount, 0, CNT_WORDS * sizeof(uint32_t), st));
@@ -1100,7 +1102,7 @@ static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup
             hipLaunchKernelGGL(k_brute_extend<QueueSrc>, dim3((total + 255) / 256), dim3(256), 0, st, ctx->brute, src, ctx->countersOn ? ctx->dStats : nullptr);
             rt_timer_end(ctx);
         } else if (b == 0 && ctx->optPacketPrimary) launch_traverse_packets(ctx, sv, src, ctx->dQCount + CNT_CURSOR(b), total, "k_extend");
-        else launch_traverse(ctx, sv, src, ctx->dQCount + CNT_CURSOR(b), total, "k_extend");
+        else launch_traverse(ctx, b == 0 ? svCamera : sv, src, ctx->dQCount + CNT_CURSOR(b), total, "k_extend");
         if (b == 0 && withShadowSetup) launch_sm_setup(ctx, sv, total, qin, ctx->dQCount);   // before shade moves the rays on
         if (b == overlapAfter) {
             const int rc = overlap_fork(ctx, sv, total);
@@ -1145,7 +1147,7 @@ static int shadowmap_frames(RtContext *ctx, uint32_t frames)
     prim.qcount = cnt + CNT_SMPRIM;
     prim.hit = ctx->dHit;
     if (ctx->optPacketPrimary) launch_traverse_packets(ctx, sv, prim, cnt + CNT_FETCH_SM0, total, "k_extend");
-    else launch_traverse(ctx, sv, prim, cnt + CNT_FETCH_SM0, total, "k_extend");
+    else launch_traverse(ctx, rt_scene_view(ctx, true), prim, cnt + CNT_FETCH_SM0, total, "k_extend");
     launch_sm_setup(ctx, sv, total, ctx->dRay[0], cnt + CNT_SMPRIM);
     launch_shadow_rays(ctx, sv, total);
     RT_HIP(ctx, hipGetLastError());
@@ -1324,7 +1326,7 @@ int rt_render_frames_impl(RtContext *ctx, const float *seeds, uint32_t nFrames)
 int rt_trace_device_impl(RtContext *ctx, const float4 *o, const float4 *d, uint32_t n, RtHitRec *hits)
 {
     if (n == 0) return RT_OK;
-    const RtSceneView sv = rt_scene_view(ctx);
+    const RtSceneView sv = rt_scene_view(ctx, true);
     RT_HIP(ctx, hipMemsetAsync(ctx->dQCount + CNT_FETCH_TRACE, 0, sizeof(uint32_t), ctx->stream));
     ArraySrc src;
     src.org = o;
@@ -1378,7 +1380,7 @@ int rt_trace_device_static_impl(RtContext *ctx, const float4 *o, const float4 *d
     }
     if (!ptr) return rt_fail(ctx, RT_E_STATE, "no static scratch array on device %d", ctx->device);
     if (n == 0) return RT_OK;
-    RtSceneView sv = rt_scene_view(ctx);
+    RtSceneView sv = rt_scene_view(ctx, true);
     sv.stats = nullptr;
     sv.errorFlag = ptr + 32;
     sv.stackSpill = ptr + RT_STATIC_HEAD_WORDS;

@@ -49,7 +49,7 @@ struct __attribute__((aligned(16))) RtQNode4 {
     uint32_t child[4];                    // index | RT_LEAF_BIT
 };
 static_assert(sizeof(RtQNode4) == 64, "wide node layout");
-#define RT_QH_NO_BOX 0xFBFF7BFFu          // low plane +65504, high plane -65504: near beyond far for every ray
+// (RT_QH_NO_BOX, the box of an unused place, is defined beside the slab test in rt_qh.h)
 
 // Intersection record of the triangle at sorted leaf j, 64 B: v0 and the two
 // edge vectors (the same subtractions IntersectTriangle_MT97 performs first)
@@ -272,7 +272,8 @@ struct RtContext {
     bool optCasterBox = true;             // shadow rays that cannot meet a shadow caster are not walked
     bool optFirstHitShadow = true;        // shadow rays that cannot meet a non-casting triangle stop at their first hit
     bool optOverlapShadow = true;         // walk the shadow rays while the later bounces run (render.hip, overlap_fork)
-    bool optPruneByDistance = true;       // boxes beyond the closest hit found so far are not entered (RT_OPT_PRUNE_BY_DISTANCE)
+    int optPruneByDistance = 1;           // RT_OPT_PRUNE_BY_DISTANCE: boxes beyond the closest hit found so far are not entered by 0 no ray, 1 the rays
+                                          // whose hits are not handed out (bounce rays, soft-shadow rays), 2 every ray
     bool optShareLongWalks = true;        // idle lanes take over parts of the walks a launch ends with (RT_OPT_SHARE_LONG_WALKS)
     bool optEagerShadowMap = true;        // rt_dispatch starts the ShadowMap pass of its frame (render.hip, rt_dispatch_impl)
     int eagerShadow = 0;                  // RT_EAGER_*: what rt_dispatch left for rt_dispatch_shadowmap
@@ -334,7 +335,8 @@ int rt_readback_bvh_impl(RtContext *ctx, uint32_t *morton, uint32_t *sortedIdx, 
 void rt_free_build(RtContext *ctx);
 
 // render.hip
-RtSceneView rt_scene_view(RtContext *ctx);
+// firstHitsHandedOut: the launch walks rays whose hits the caller gets to see, triangle by triangle (camera rays, rt_trace_rays*)
+RtSceneView rt_scene_view(RtContext *ctx, bool firstHitsHandedOut = false);
 int rt_alloc_render(RtContext *ctx);
 // What a call borrows and gives back when it ends, however it ends (every error path returns early): scratch
 // buffers and events.  The stream is drained first, because launches in flight may still use the buffers.

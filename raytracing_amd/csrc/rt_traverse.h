@@ -3,10 +3,14 @@
 // Semantics are those of the reference's BVHRayTrace
 // (Assets/Shaders/BVH/BVHRayTracing.cginc:27-133 with IntersectTriangle_MT97,
 // Assets/Shaders/RayTracing/BruteForceRayTracing.cginc:166-204): every node
-// whose box the ray passes is visited (no distance pruning), a leaf's triangle
+// whose box the ray passes is visited (the reference has no distance test), a leaf's triangle
 // is tested when its own box passes, the closest hit wins with strict '<', so
 // on equal distances the triangle met first in the reference's depth-first
 // order (left leaf, right leaf, right subtree, left subtree) is kept.
+// One option departs from "every box the ray passes": launches whose scene view carries a finite pruneScale
+// (RT_OPT_PRUNE_BY_DISTANCE: by default the bounce and soft-shadow rays, never the rays whose hits are handed out)
+// leave out boxes that begin beyond the closest hit held -- the same hit except where Moller-Trumbore's distance of
+// a triangle is far off (rtcore.h says when); with pruneScale = +inf the walk below is exact by construction.
 //
 // What is different is only HOW the same result is computed:
 //   * Inner nodes are a filter, not a decision.  With finite, non-zero direction
@@ -60,9 +64,11 @@
 #define TRV_WALK_NUM 1u         // leave the node phase when fewer than NUM/DEN of the lanes that still have nodes to visit
 #define TRV_WALK_DEN 2u         // can go on (the rest wait for triangle tests); 3/4, 3/5, 1/2, 2/5, 1/3 with two levels per step: 87.7 / 85.8 / 85.1 / 85.3 / 86.8 ms per image
 #endif
-// Boxes that begin beyond the closest hit a ray holds are not entered (RT_OPT_PRUNE_BY_DISTANCE): "beyond" with this
-// much room, because the distance of a hit (Moller-Trumbore) and the entry distance of a box (slab test) are two
-// different float computations and only agree to rounding.
+// Boxes that begin beyond the closest hit a ray holds are not entered by the launches that use the rule
+// (RT_OPT_PRUNE_BY_DISTANCE): "beyond" with this much room, because the distance of a hit (Moller-Trumbore) and the
+// entry distance of a box (slab test) are two different float computations and only agree to rounding -- to rounding
+// of a quotient whose divisor can be nearly all rounding error (a ray nearly in a triangle's plane), which is why
+// the rule is not applied to rays whose hits are handed out.
 #define RT_PRUNE_SCALE 1.015625f
 // Long walks are shared out at the end of a launch (RT_OPT_SHARE_LONG_WALKS, traverse_rays): once the launch has no
 // more rays to deal and at least this many lanes of a wave are idle, idle lanes take over stacked subtrees of lanes that
@@ -335,8 +341,8 @@ __device__ __forceinline__ void exact_walk(const RtSceneView &sv, const rt_f3 o,
 #endif
 // Per-lane state of the walk through the half-float nodes.
 struct WalkState {
-    uint32_t node, sp, npend, tos, below;
-    bool popped;
+    uint32_t node, sp, npend;
+    uint32_t tos;        // one level per step: the stack's top level, mirrored; both walks: TRV_REDO = this ray takes the exact walk next
 };
 
 // The node phase of a wave: walk the tree, queue triangles whose box may pass.  A lane whose pending list has no
@@ -351,8 +357,8 @@ struct WalkState {
 // +inf.  A triangle in a box left out lies, to rounding, behind the hit the ray already holds and could not replace
 // it; "to rounding" is where this differs from the reference's walk, which enters every box the ray passes: the two
 // return different hits only if Moller-Trumbore puts a triangle more than 1.5 % nearer than the box that holds it,
-// which takes a ray within 3e-5 rad of the triangle's plane (more for slivers: the bound is 5e-7 / (that angle x the
-// sine of the angle between the triangle's edges) relative).
+// which takes a ray within a few microradians of the triangle's plane (more for slivers: the relative error is about
+// 6e-8 / (that angle x the sine of the angle between the triangle's edges)).
 template <uint32_t OCT, bool COUNT, bool NEAR>
 __device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySlab &slab, WalkState &w, uint32_t *stk, uint32_t *pend,
                                            uint32_t *spill, const uint32_t spillLanes, uint32_t cnt[3], const bool feedExhausted,
@@ -361,6 +367,11 @@ __device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySla
     // shareTrips (wave-uniform): steps this phase may take while lanes idle that could take over part of a walk
     // (0xFFFFFFFF: no such limit)
     uint32_t trips = 0;
+    // After a pop the level below the old top becomes the mirrored one, at the lane's next step or when the phase ends
+    // (the read of that level is then long back).  `popped` is a 32-bit lane value, not a boolean: a boolean lives as a
+    // bit of a scalar lane mask, which the compiler rebuilds from a vector register when lanes leave and rejoin a loop --
+    // from a register that holds nothing for a lane that left early; a word per lane is never rebuilt.
+    uint32_t popped = 0u, below = TRV_DONE;
     for (;;) {
         // (one ballot per comparison, combined as scalar masks: the ballot of a conjunction is made by way of a vector register)
         const bool busy = w.node != TRV_DONE, room = w.npend <= TRV_PEND_CAP - 2;
@@ -376,8 +387,8 @@ __device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySla
         if (act) {
             const uint4 *np = (const uint4 *)(sv.qnodes + w.node);
             uint4 qa = np[0], qb = np[1];
-            w.tos = w.popped ? w.below : w.tos;                  // after the loads are on their way
-            w.popped = false;
+            w.tos = popped != 0u ? below : w.tos;                // after the loads are on their way
+            popped = 0u;
             // keep the fetch at two 16-byte loads per lane (the compiler would otherwise split the second)
             asm volatile("" : "+v"(qb.x), "+v"(qb.y), "+v"(qb.z), "+v"(qb.w));
             const uint32_t l = qb.z, rr = qb.w;
@@ -402,14 +413,14 @@ __device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySla
                 // the next node can be fetched; the level below is read now and taken over at the
                 // start of this lane's next step (level 0 holds TRV_DONE).
                 stk[w.sp * TRV_THREADS] = later;
-                w.below = stk[(w.sp > 1u ? w.sp - 2u : 0u) * TRV_THREADS];
+                below = stk[(w.sp > 1u ? w.sp - 2u : 0u) * TRV_THREADS];
                 const bool both = goL && goR, none = !(goL || goR);
                 uint32_t next = goR ? rr : l;
                 next = both ? first : next;
                 next = none ? w.tos : next;
                 w.node = next;
                 w.tos = both ? later : w.tos;
-                w.popped = none;
+                popped = none ? 1u : 0u;
                 w.sp += both ? 1u : 0u;
                 w.sp -= none ? 1u : 0u;
             } else if (__builtin_expect(w.sp > RT_STACK_DEPTH, 0)) {
@@ -445,6 +456,7 @@ __device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySla
             }
         }
     }
+    w.tos = popped != 0u ? below : w.tos;
 }
 
 // The node phase over the 64-byte records that hold two levels of the tree (RtQNode4): one step fetches the boxes of up
@@ -456,14 +468,16 @@ template <uint32_t OCT>
 __device__ __forceinline__ bool wide_box(const RtRaySlab &slab, uint32_t wx, uint32_t wy, uint32_t wz, uint32_t ref, const float limit, float *tnear)
 {
     const bool maybe = OCT < 8u ? rt_slab_maybe_octant_near<(OCT & 7u)>(slab, wx, wy, wz, tnear) : rt_slab_maybe_near(slab, wx, wy, wz, tnear);
-    // an unused place holds a box whose low planes lie above its high planes: the octant test never passes it, the
-    // test that sorts a slab's two planes would
+    // an unused place holds a box whose low planes lie above its high planes: the octant test never passes it for a ray
+    // that is walked here (rt_slab_rejects_empty_box, checked when the ray is dealt), the test that sorts a slab's two
+    // planes would
     return maybe && *tnear <= limit && (OCT < 8u || ref != RT_INVALID);
 }
 
-template <uint32_t OCT>
+// COUNT: every place of a record that holds a child is a box tested (cnt[0]).
+template <uint32_t OCT, bool COUNT>
 __device__ __forceinline__ void node_phase_wide(const RtSceneView &sv, const RtRaySlab &slab, WalkState &w, uint32_t *stk, uint32_t *pend,
-                                                uint32_t *spill, const uint32_t spillLanes, const bool feedExhausted, const float limit,
+                                                uint32_t *spill, const uint32_t spillLanes, uint32_t cnt[3], const bool feedExhausted, const float limit,
                                                 const uint32_t shareTrips)
 {
     uint32_t trips = 0;
@@ -479,6 +493,7 @@ __device__ __forceinline__ void node_phase_wide(const RtSceneView &sv, const RtR
             const uint4 *np = (const uint4 *)(sv.wnodes + w.node);
             const uint4 qa = np[0], qb = np[1], qc = np[2], qd = np[3];
             const uint32_t r0 = qd.x, r1 = qd.y, r2 = qd.z, r3 = qd.w;
+            if (COUNT) cnt[0] += (r0 != RT_INVALID ? 1u : 0u) + (r1 != RT_INVALID ? 1u : 0u) + (r2 != RT_INVALID ? 1u : 0u) + (r3 != RT_INVALID ? 1u : 0u);
             float n0, n1, n2, n3;
             const bool h0 = wide_box<OCT>(slab, qa.x, qa.y, qa.z, r0, limit, &n0);
             const bool h1 = wide_box<OCT>(slab, qa.w, qb.x, qb.y, r1, limit, &n1);
@@ -585,7 +600,7 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
 #endif
     const bool sharing = !COUNT && sv.shareWalks != 0u;
     WalkState w;
-    w.node = TRV_DONE; w.sp = 0; w.npend = 0; w.tos = TRV_DONE; w.below = TRV_DONE; w.popped = false;
+    w.node = TRV_DONE; w.sp = 0; w.npend = 0; w.tos = TRV_DONE;
     rt_f3 o = rt_splat3(0.0f), d = rt_splat3(0.0f), r = rt_splat3(0.0f);
     RtRaySlab slab;
     memset(&slab, 0, sizeof slab);
@@ -619,11 +634,10 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                 stk[0] = TRV_DONE;                             // what the last pop of a ray returns
                 w.sp = 1;
                 w.tos = TRV_DONE;
-                w.popped = false;
                 w.npend = 0;
                 w.node = TRV_DONE;
                 if (COUNT) nRays++;
-                if (__builtin_expect(rt_ray_needs_exact_walk(o, d) || !rt_slab_finite(slab), 0)) {
+                if (__builtin_expect(rt_ray_needs_exact_walk(o, d) || !rt_slab_finite(slab) || !rt_slab_rejects_empty_box(slab), 0)) {
                     w.tos = TRV_REDO;                          // the whole walk at once, after the node phase; retired below
                 } else if (sv.nTriangles != 0) {
                     if (COUNT) cnt[0]++;
@@ -678,7 +692,6 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                         stk[0] = TRV_DONE;
                         w.sp = 1;
                         w.tos = TRV_DONE;
-                        w.popped = false;
                         w.npend = 0;
                         hasRay = true;
                         share = 1u | (D << 16) | (1u << 24);
@@ -705,17 +718,17 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
             const uint32_t oct = uniform ? ((sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u)) : 8u;
             constexpr bool NEAR = true;                              // every kind of ray gains: a hit found sooner, or a closer one
             const float limit = h.t * sv.pruneScale;                 // +inf without a hit, or with the option off
-            if (!COUNT && sv.wnodes != nullptr) {
+            if (sv.wnodes != nullptr) {
                 switch (oct) {
-                case 0: node_phase_wide<0>(sv, slab, w, stk, pend, spill, spillLanes, feed.exhausted, limit, shareTrips); break;
-                case 1: node_phase_wide<1>(sv, slab, w, stk, pend, spill, spillLanes, feed.exhausted, limit, shareTrips); break;
-                case 2: node_phase_wide<2>(sv, slab, w, stk, pend, spill, spillLanes, feed.exhausted, limit, shareTrips); break;
-                case 3: node_phase_wide<3>(sv, slab, w, stk, pend, spill, spillLanes, feed.exhausted, limit, shareTrips); break;
-                case 4: node_phase_wide<4>(sv, slab, w, stk, pend, spill, spillLanes, feed.exhausted, limit, shareTrips); break;
-                case 5: node_phase_wide<5>(sv, slab, w, stk, pend, spill, spillLanes, feed.exhausted, limit, shareTrips); break;
-                case 6: node_phase_wide<6>(sv, slab, w, stk, pend, spill, spillLanes, feed.exhausted, limit, shareTrips); break;
-                case 7: node_phase_wide<7>(sv, slab, w, stk, pend, spill, spillLanes, feed.exhausted, limit, shareTrips); break;
-                default: node_phase_wide<8>(sv, slab, w, stk, pend, spill, spillLanes, feed.exhausted, limit, shareTrips); break;
+                case 0: node_phase_wide<0, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 1: node_phase_wide<1, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 2: node_phase_wide<2, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 3: node_phase_wide<3, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 4: node_phase_wide<4, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 5: node_phase_wide<5, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 6: node_phase_wide<6, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 7: node_phase_wide<7, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                default: node_phase_wide<8, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
                 }
             } else
             switch (oct) {
@@ -748,7 +761,7 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
         if (COUNT) {
             for (uint32_t k = 0; __ballot(k < npend) != 0ull; ++k)
                 if (k < npend) {
-                    const bool boxed = tri_test<COUNT>(sv, pend[k * TRV_THREADS], o, d, r, h);
+                    const bool boxed = tri_test<COUNT>(sv, pend[k * TRV_THREADS] & ~RT_LEAF_BIT, o, d, r, h);   // (the two-level walk queues references with their leaf bit)
                     cnt[1]++;
                     cnt[2] += boxed ? 1u : 0u;
                 }

@@ -101,33 +101,44 @@ def test_first_hit_bit_exact(core, oracle, name, packets):
     o = np.concatenate([o1, o2, o3])
     d = np.concatenate([d1, d2, d3])
     core.set_option(wire.OPT_PACKET_TRACE, packets)
-    core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 0)  # the walk whose work the checker counts: every box the ray passes
+    # Caller rays enter every box they pass (RT_OPT_PRUNE_BY_DISTANCE 0 and the default 1 alike): the walk whose work
+    # the checker counts.  2 leaves boxes beyond the closest hit out for these rays as well.
     core.enable_counters(True)
     core.reset_stats()
     got = core.trace_rays(o, d)
     st = core.stats()
-    core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 1)
+    core.set_option(wire.OPT_WIDE_NODES, 0)
+    core.reset_stats()
+    got_narrow = core.trace_rays(o, d)
+    st_narrow = core.stats()
+    core.set_option(wire.OPT_WIDE_NODES, 1)
+    core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 2)
     core.reset_stats()
     got_counting_fewer = core.trace_rays(o, d)
     st_fewer = core.stats()
     core.enable_counters(False)
-    got_plain = core.trace_rays(o, d)             # the build without counters is a different kernel, and leaves out
-    core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 0)  # boxes beyond the closest hit unless told to enter them all
+    got_fewer = core.trace_rays(o, d)             # the build without counters is a different kernel
+    core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 0)
     got_every_box = core.trace_rays(o, d)
     core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 1)
+    got_plain = core.trace_rays(o, d)
     core.set_option(wire.OPT_PACKET_TRACE, False)
     for k in ("triangle", "t", "u", "v"):
         H.assert_bits_equal(got_plain[k], got[k], f"{k}: counting vs plain kernel")
-        H.assert_bits_equal(got_every_box[k], got[k], f"{k}: counting vs plain kernel entering every box")
+        H.assert_bits_equal(got_narrow[k], got[k], f"{k}: two levels of the tree per step vs one")
+        H.assert_bits_equal(got_every_box[k], got[k], f"{k}: option 0 vs the default")
+        H.assert_bits_equal(got_fewer[k], got[k], f"{k}: boxes beyond the closest hit left out")
         H.assert_bits_equal(got_counting_fewer[k], got[k], f"{k}: counting kernel, boxes beyond the closest hit left out")
     assert st_fewer["rays"] == st["rays"] and st_fewer["hits"] == st["hits"]
     assert st_fewer["internalVisits"] <= st["internalVisits"] and st_fewer["triTests"] <= st["triTests"]
     if not packets and name in ("cornell", "soup20k"):
         assert st_fewer["internalVisits"] < st["internalVisits"]
     want = orc.trace(o, d)                        # the reference's walk
-    # work counters: the packet walker takes the reference's walk node for node; the one-ray-per-lane
-    # walker tests 16-bit outward-rounded boxes, restated on the CPU by trace(grid=True)
-    want_counters = want["counters"] if packets else orc.trace(o, d, grid=True)["counters"]
+    # work counters: the packet walker takes the reference's walk node for node; the one-ray-per-lane walker tests
+    # half-float outward-rounded boxes of its own tree, two levels per step by default (restated on the CPU by
+    # trace(wide=True)) or one (trace(grid=True))
+    want_counters = want["counters"] if packets else orc.trace(o, d, wide=True)["counters"]
+    want_narrow = want["counters"] if packets else orc.trace(o, d, grid=True)["counters"]
     H.assert_bits_equal(got["triangle"], want["triangle"], "first-hit triangle id")
     H.assert_bits_equal(got["t"], want["t"], "hit distance")
     hit = want["triangle"] != 0xFFFFFFFF
@@ -135,6 +146,7 @@ def test_first_hit_bit_exact(core, oracle, name, packets):
     H.assert_bits_equal(got["v"][hit], want["v"][hit], "barycentric v")
     for k in ("rays", "internalVisits", "leafVisits", "triTests", "hits"):
         assert st[k] == want_counters[k], f"counter {k}: gpu {st[k]} vs oracle {want_counters[k]}"
+        assert st_narrow[k] == want_narrow[k], f"counter {k}, one level per step: gpu {st_narrow[k]} vs oracle {want_narrow[k]}"
     for k in ("rays", "triTests", "hits"):        # the same whichever way the tree is walked
         assert st[k] == want["counters"][k]
     if name in ("cornell", "soup20k"):
@@ -345,7 +357,7 @@ def test_long_walks_shared_between_lanes_do_not_change_a_bit(core, oracle):
                 c.bvh_build()
                 for o, d in rays:
                     want = orc.trace(o, d)
-                    for prune, wide in ((1, 0), (0, 0), (1, 1), (0, 1)):
+                    for prune, wide in ((2, 0), (0, 0), (2, 1), (1, 1)):   # (caller rays enter every box with 0 and with the default 1)
                         c.set_option(wire.OPT_PRUNE_BY_DISTANCE, prune)
                         c.set_option(wire.OPT_WIDE_NODES, wide)
                         for on in (1, 0):

@@ -226,6 +226,13 @@ def test_grid_walk_returns_the_reference_walks_hits(oracle, name):
     assert got["counters"]["triTests"] == ref["counters"]["triTests"]
     assert got["counters"]["hits"] == ref["counters"]["hits"]
     assert (ref["triangle"] != 0xFFFFFFFF).sum() > 50
+    # ... and two levels of that tree per step, the default walker's way: a child's own box is never looked at, only
+    # its children's, so fewer steps, the same triangles
+    wide = orc.trace(o, d, wide=True)
+    for k in ("triangle", "t", "u", "v"):
+        H.assert_bits_equal(wide[k], ref[k], k + " (two levels per step)")
+    assert wide["counters"]["triTests"] == ref["counters"]["triTests"] and wide["counters"]["hits"] == ref["counters"]["hits"]
+    assert wide["counters"]["leafVisits"] >= got["counters"]["leafVisits"]       # an unopened parent box filters nothing
 
 
 def _half_values(bits):
@@ -519,3 +526,34 @@ def test_grid_walk_keeps_the_reference_winner_among_coincident_triangles(oracle)
     assert (a["triangle"] != 0xFFFFFFFF).sum() > 2000
     assert (a["triangle"] == b["triangle"]).all() and a["t"].tobytes() == b["t"].tobytes()
     assert a["u"].tobytes() == b["u"].tobytes() and a["v"].tobytes() == b["v"].tobytes()
+
+
+def test_leaving_out_boxes_beyond_the_closest_hit_is_not_exact(oracle):
+    """Why camera rays and caller rays enter every box by default (RT_OPT_PRUNE_BY_DISTANCE): on rays that run nearly
+    inside the planes of large triangles and slivers (tests/adversarial.py) Moller-Trumbore puts some of those
+    triangles in front of the well-shaped triangle before them, the reference's walk -- which tests every triangle
+    whose box the ray passes -- returns them, and a walk that skips boxes beginning 1/64 or 1/16 beyond the hit it
+    holds does not.  The walks that enter every box (one and two levels of the tree per step) agree with the
+    reference's walk bit for bit on the same rays."""
+    from tests import adversarial
+    sc, cells = adversarial.grazing_cells(512)
+    o, d = adversarial.grazing_rays(cells, 4000)
+    orc = oracle.Oracle(sc).build()
+    assert orc.grid()[0]
+    ref = orc.trace(o, d)
+    for kind in ("grid", "wide"):
+        got = orc.trace(o, d, **{kind: True})
+        for k in ("triangle", "t", "u", "v"):
+            H.assert_bits_equal(got[k], ref[k], f"{k} ({kind})")
+    assert (ref["triangle"] != 0xFFFFFFFF).mean() > 0.99
+    on_fans = (ref["triangle"] % 4 != 0) & (ref["triangle"] != 0xFFFFFFFF)     # triangle 4k is cell k's well-shaped one
+    assert on_fans.sum() > 100
+    changed = {}
+    for scale in (1.015625, 1.0625):
+        got = orc.trace_leaving_out_far_boxes(o, d, scale)
+        moved = np.nonzero(got["triangle"] != ref["triangle"])[0]
+        changed[scale] = len(moved)
+        assert on_fans[moved].all()                      # every changed hit: a fan triangle the pruned walk never tested
+        assert (got["t"][moved] >= ref["t"][moved]).all()
+    assert changed[1.015625] >= 10 and changed[1.0625] >= 3, changed
+    assert changed[1.0625] <= changed[1.015625]
