@@ -111,6 +111,155 @@ def cpu_baseline(sc, args):
                       f"{dt:.1f} s; every BVHRayTrace call counted (the checker walks each one)"}
 
 
+def query_ray_bytes(c):
+    """Algorithmic bytes of first-hit queries (rt_trace_rays_device): the node, leaf and triangle terms of a camera ray,
+    32 B of ray record read and a 16-B hit record written per ray; no shading inputs."""
+    return 32 * c["internalVisits"] + 28 * c["leafVisits"] + 36 * c["triTests"] + 48 * c["rays"]
+
+
+def soup_main(args, rank, world, local_rank, device, dist, barrier):
+    """--workload soup10m: the synthetic triangle soup (centres uniform in [-100, 100]^3, edge vectors uniform in
+    [-0.5, 0.5]^3, one diffuse material), BVH build timed by itself, then the traversal stress: 2^24 incoherent rays
+    (origins uniform in the box, cosine-hemisphere directions about random normals) resident in device memory, one
+    rt_trace_rays_device call per step.  The reference cannot hold this scene (524 288-triangle cap,
+    Assets/Scripts/BVH/Constants.cs:3-6).  Its tree, 2.7 GB of records, does not fit the 256 MB Infinity Cache, so
+    here HBM is the yardstick: roofline.bound = "hbm".  N ranks: every rank builds the whole tree and walks 1/N of the rays."""
+    import torch
+    n_tri, n_rays = args.triangles, args.rays
+    sc = scenes.triangle_soup(n_tri, seed=5)
+    core = native.RtCore(local_rank)
+    core.upload(sc)
+    core.bvh_build()
+    build_first_ms = core.stats()["buildMs"]
+    build = []
+    for _ in range(3):
+        core.bvh_build()
+        build.append(core.stats()["buildMs"])
+    build_ms = min(build)
+    for kv in args.option:
+        k, v = kv.split("=")
+        core.set_option(int(k), int(v))
+    o, d = scenes.stress_rays(n_rays, seed=7)
+    lo, hi = n_rays * rank // world, n_rays * (rank + 1) // world
+    n = hi - lo
+    o4 = torch.zeros((n, 4), dtype=torch.float32)
+    d4 = torch.zeros((n, 4), dtype=torch.float32)
+    o4[:, :3] = torch.from_numpy(o[lo:hi])
+    d4[:, :3] = torch.from_numpy(d[lo:hi])
+    del o, d
+    o4, d4 = o4.to(device), d4.to(device)
+    hits = torch.empty((n, 4), dtype=torch.float32, device=device)
+    torch.cuda.synchronize()
+
+    def step():
+        core.trace_rays_device(o4.data_ptr(), d4.data_ptr(), n, hits.data_ptr())
+
+    core.enable_counters(True)
+    core.reset_stats()
+    step()
+    st = core.stats()
+    core.enable_counters(False)
+    local = {k: int(st[k]) for k in COUNT_KEYS}
+    counts = torch.tensor([local[k] for k in COUNT_KEYS], dtype=torch.int64, device=device if args.backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(counts)
+    total = {k: int(v) for k, v in zip(COUNT_KEYS, counts.tolist())}
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    torch.cuda.synchronize()
+    core.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    core.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    hit_share = float((hits[:, 3].view(torch.int32) != -1).float().mean().item())
+    # the launch by itself, HIP events on the library's stream
+    roof_steps = 0 if args.no_kernel_timing else min(args.steps, 3)
+    core.reset_stats()
+    core.enable_kernel_timing(roof_steps > 0)
+    for _ in range(roof_steps):
+        step()
+    core.synchronize()
+    ms_launch, n_launch = core.kernel_time("k_trace")
+    # the same rays with boxes beyond the closest hit left out (RT_OPT_PRUNE_BY_DISTANCE 2: not exact for every ray)
+    pruned_ms = None
+    if roof_steps and not args.option:
+        core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 2)
+        core.reset_stats()
+        for _ in range(roof_steps):
+            step()
+        core.synchronize()
+        pm, pn = core.kernel_time("k_trace")
+        pruned_ms = pm / max(pn, 1)
+        core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 1)
+    core.enable_kernel_timing(False)
+    if world > 1:
+        et = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+        elapsed = float(et[0].item())
+    workload_name = (f"{n_tri}-triangle random soup, {n_rays} incoherent rays per step (origins uniform in the box, cosine-hemisphere "
+                     f"directions), first-hit queries on rays resident in device memory")
+    if rank == 0:
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic_soup.json")
+        measured = json.load(open(tpath)).get("k_traverse<ArraySrc>", {}) if os.path.exists(tpath) else {}
+        same = measured.get("workload") == workload_name and measured.get("n_gpus") == world
+        alg = query_ray_bytes(local)
+        roofline = None
+        if n_launch:
+            dur = ms_launch / n_launch * 1e-3
+            gbps = alg / dur / 1e9
+            roofline = {"bound": "hbm", "achieved": round(gbps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbps / HBM_PEAK_GBS, 4),
+                        "traffic": measured.get("hbm_bytes_per_launch") if same else None, "kernel": "k_traverse<ArraySrc>",
+                        "launches": int(n_launch), "avg_launch_ms": round(ms_launch / n_launch, 4), "rays_per_launch": n,
+                        "algorithmic_bytes_per_launch": int(alg), "algorithmic_bytes_per_ray": round(alg / max(local["rays"], 1), 1),
+                        "note": "achieved = algorithmic bytes (32 B per box tested, 28 B per leaf box, 36 B per triangle tested, 48 B of ray and "
+                                "hit record per ray; counts from the counting kernels of the same launch) / launch time by HIP events. "
+                                "traffic = memory-side bytes per launch from the committed rocprofv3 --pmc passes of this command "
+                                "(FETCH_SIZE x 2 + WRITE_SIZE, profiles/pmc_traffic_soup.json)"}
+            if same:
+                hb = measured["hbm_bytes_per_launch"] / dur / 1e9
+                roofline["measured"] = {"hbm_gbps": round(hb, 1), "hbm_frac": round(hb / HBM_PEAK_GBS, 4),
+                                        "traffic_over_algorithmic": round(measured["hbm_bytes_per_launch"] / alg, 3),
+                                        "valu_issue_frac": round(measured.get("valu_instructions_per_launch", 0) / dur / 1e9 / VALU_PEAK_GINST, 4),
+                                        "counters": {k: measured.get(k) for k in ("l2_hit_rate", "lane_utilisation", "waves_per_simd", "valu_busy",
+                                                                                  "td_busy", "ta_busy")},
+                                        "pmc_sources_match": measured.get("source_id") == source_id()}
+        build_bytes = 436.0 * n_tri
+        out = {
+            "metric": "Mrays/s", "value": round(n_rays * args.steps / elapsed / 1e6, 3), "unit": "Mrays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload_name, "parallelism": f"rays split over {world} GPU(s), tree built on every GPU"},
+            "hit_share": round(hit_share, 4),
+            "traversal_counts_per_step": total,
+            "ms_per_step_boxes_beyond_the_closest_hit_left_out": None if pruned_ms is None else round(pruned_ms, 3),
+            "bvh_build": {"ms": round(build_ms, 3), "first_ms": round(build_first_ms, 3), "mtris_per_s": round(n_tri / build_ms / 1e3, 1),
+                          "algorithmic_bytes_per_triangle": 436, "achieved_gbps": round(build_bytes / (build_ms * 1e-3) / 1e9, 1),
+                          "frac_of_hbm_peak": round(build_bytes / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "note": "436 B per triangle is the contract figure for the reference's tree alone; this build also makes the "
+                                  "traversal tree, its rotations and the leaf records (about 2.6 kB moved per triangle)"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle_py
+            orc = oracle_py.Oracle(sc).build()
+            m = 1 << 18
+            oc = o4[:m, :3].cpu().numpy().copy()
+            dc = d4[:m, :3].cpu().numpy().copy()
+            t1 = time.time()
+            orc.trace(oc, dc)
+            dt = time.time() - t1
+            out["cpu_baseline"] = {"value": round(m / dt / 1e6, 3), "unit": "Mrays/s", "cores": int(oracle_py.lib().orc_num_threads()), "kind": "port",
+                                   "sample": f"the first {m} of the same rays through the checker's walk of the reference's tree, {dt:.1f} s "
+                                             f"(its build of the {n_tri}-triangle scene not timed)"}
+        print(json.dumps(out), flush=True)
+    core.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,6 +278,9 @@ def main():
     ap.add_argument("--no-dropin", action="store_true", help="skip the per-frame drop-in leg")
     ap.add_argument("--plain-order", action="store_true", help="one launch after the other on one stream (for hardware-counter "
                                                                "passes, which see each kernel by itself)")
+    ap.add_argument("--option", action="append", default=[], metavar="K=V", help="rt_set_option(K, V) before rendering (experiments)")
+    ap.add_argument("--triangles", type=int, default=10_000_000, help="soup10m: triangles")
+    ap.add_argument("--rays", type=int, default=1 << 24, help="soup10m: rays per step")
     args = ap.parse_args()
 
     import torch
@@ -154,6 +306,12 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    if args.workload == "soup10m":
+        soup_main(args, rank, world, local_rank, device, dist, barrier)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
     # ---- scene: generated on rank 0, broadcast over RCCL, built on every GPU
     sc = make_scene(args) if rank == 0 else None
     if world > 1:
@@ -169,6 +327,9 @@ def main():
     core.set_params(params)
     if args.plain_order:
         core.set_option(wire.OPT_OVERLAP_SHADOW, 0)
+    for kv in args.option:
+        k, v = kv.split("=")
+        core.set_option(int(k), int(v))
     seeds = scenes.frame_seeds(args.spp, seed=1)
     gatherer = rtdist.TileGatherer(args.width, args.height, 64, comm_device)
     staging = None if comm_device == device else torch.zeros(gatherer.n_local * 4, dtype=torch.float32, device=device)

@@ -464,18 +464,22 @@ __device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySla
 // may pass and stacks the others.  Same stack as node_phase (level 0 holds TRV_DONE, entries are node numbers of the
 // same tree), without the register copy of its top; same end test; same results, because inner nodes are only a filter
 // (a box that is not tested -- the child's, between a node and its grandchildren -- cannot lose a triangle).
-template <uint32_t OCT>
+template <uint32_t OCT, bool ORDERED>
 __device__ __forceinline__ bool wide_box(const RtRaySlab &slab, uint32_t wx, uint32_t wy, uint32_t wz, uint32_t ref, const float limit, float *tnear)
 {
     const bool maybe = OCT < 8u ? rt_slab_maybe_octant_near<(OCT & 7u)>(slab, wx, wy, wz, tnear) : rt_slab_maybe_near(slab, wx, wy, wz, tnear);
     // an unused place holds a box whose low planes lie above its high planes: the octant test never passes it for a ray
     // that is walked here (rt_slab_rejects_empty_box, checked when the ray is dealt), the test that sorts a slab's two
     // planes would
-    return maybe && *tnear <= limit && (OCT < 8u || ref != RT_INVALID);
+    return maybe && (!ORDERED || *tnear <= limit) && (OCT < 8u || ref != RT_INVALID);
 }
 
 // COUNT: every place of a record that holds a child is a box tested (cnt[0]).
-template <uint32_t OCT, bool COUNT>
+// ORDERED: the walk goes front to back and leaves out what begins beyond `limit`.  A walk that enters every box a ray
+// passes and ends only when all are visited (limit = +inf, no stop at a first hit) gains nothing from an order: without
+// it the step goes on with the first place that is to be visited and stacks the others as they come, no distances
+// sorted (a quarter of the step's vector instructions).
+template <uint32_t OCT, bool COUNT, bool ORDERED>
 __device__ __forceinline__ void node_phase_wide(const RtSceneView &sv, const RtRaySlab &slab, WalkState &w, uint32_t *stk, uint32_t *pend,
                                                 uint32_t *spill, const uint32_t spillLanes, uint32_t cnt[3], const bool feedExhausted, const float limit,
                                                 const uint32_t shareTrips)
@@ -495,10 +499,10 @@ __device__ __forceinline__ void node_phase_wide(const RtSceneView &sv, const RtR
             const uint32_t r0 = qd.x, r1 = qd.y, r2 = qd.z, r3 = qd.w;
             if (COUNT) cnt[0] += (r0 != RT_INVALID ? 1u : 0u) + (r1 != RT_INVALID ? 1u : 0u) + (r2 != RT_INVALID ? 1u : 0u) + (r3 != RT_INVALID ? 1u : 0u);
             float n0, n1, n2, n3;
-            const bool h0 = wide_box<OCT>(slab, qa.x, qa.y, qa.z, r0, limit, &n0);
-            const bool h1 = wide_box<OCT>(slab, qa.w, qb.x, qb.y, r1, limit, &n1);
-            const bool h2 = wide_box<OCT>(slab, qb.z, qb.w, qc.x, r2, limit, &n2);
-            const bool h3 = wide_box<OCT>(slab, qc.y, qc.z, qc.w, r3, limit, &n3);
+            const bool h0 = wide_box<OCT, ORDERED>(slab, qa.x, qa.y, qa.z, r0, limit, &n0);
+            const bool h1 = wide_box<OCT, ORDERED>(slab, qa.w, qb.x, qb.y, r1, limit, &n1);
+            const bool h2 = wide_box<OCT, ORDERED>(slab, qb.z, qb.w, qc.x, r2, limit, &n2);
+            const bool h3 = wide_box<OCT, ORDERED>(slab, qc.y, qc.z, qc.w, r3, limit, &n3);
             const bool l0 = (r0 & RT_LEAF_BIT) != 0, l1 = (r1 & RT_LEAF_BIT) != 0, l2 = (r2 & RT_LEAF_BIT) != 0, l3 = (r3 & RT_LEAF_BIT) != 0;
             // leaves whose box may pass: every store happens, the count moves on only where it is needed (the reference
             // goes in as it is, leaf bit and all: the triangle phase takes the bit off)
@@ -512,21 +516,30 @@ __device__ __forceinline__ void node_phase_wide(const RtSceneView &sv, const RtR
             w.npend += (l3 && h3) ? 1u : 0u;
             // internal nodes to visit: the nearest one next, the others on the stack
             const bool g0 = !l0 && h0, g1 = !l1 && h1, g2 = !l2 && h2, g3 = !l3 && h3;
-            const float k0 = g0 ? n0 : rt_inf(), k1 = g1 ? n1 : rt_inf(), k2 = g2 ? n2 : rt_inf(), k3 = g3 ? n3 : rt_inf();
-            // all four in the order the ray enters them (a sorting network of five exchanges): the nearest next, the
-            // others stacked farthest first
-            float s0 = k0, s1 = k1, s2 = k2, s3 = k3;
-            uint32_t t0 = r0, t1 = r1, t2 = r2, t3 = r3;
-#define TRV_EXCHANGE(a, b, ra, rb) { const bool x_ = b < a; const float lo_ = x_ ? b : a, hi_ = x_ ? a : b; const uint32_t rl_ = x_ ? rb : ra, rh_ = x_ ? ra : rb; a = lo_; b = hi_; ra = rl_; rb = rh_; }
-            TRV_EXCHANGE(s0, s1, t0, t1)
-            TRV_EXCHANGE(s2, s3, t2, t3)
-            TRV_EXCHANGE(s0, s2, t0, t2)
-            TRV_EXCHANGE(s1, s3, t1, t3)
-            TRV_EXCHANGE(s1, s2, t1, t2)
-#undef TRV_EXCHANGE
             const bool any = g0 || g1 || g2 || g3;
+            uint32_t t0 = r0, t1 = r1, t2 = r2, t3 = r3;                 // t0 next; t3, t2, t1 stacked in that order where p0, p1, p2 say so
+            bool p0, p1, p2;
+            if (ORDERED) {
+                const float k0 = g0 ? n0 : rt_inf(), k1 = g1 ? n1 : rt_inf(), k2 = g2 ? n2 : rt_inf(), k3 = g3 ? n3 : rt_inf();
+                // all four in the order the ray enters them (a sorting network of five exchanges): the nearest next, the
+                // others stacked farthest first
+                float s0 = k0, s1 = k1, s2 = k2, s3 = k3;
+#define TRV_EXCHANGE(a, b, ra, rb) { const bool x_ = b < a; const float lo_ = x_ ? b : a, hi_ = x_ ? a : b; const uint32_t rl_ = x_ ? rb : ra, rh_ = x_ ? ra : rb; a = lo_; b = hi_; ra = rl_; rb = rh_; }
+                TRV_EXCHANGE(s0, s1, t0, t1)
+                TRV_EXCHANGE(s2, s3, t2, t3)
+                TRV_EXCHANGE(s0, s2, t0, t2)
+                TRV_EXCHANGE(s1, s3, t1, t3)
+                TRV_EXCHANGE(s1, s2, t1, t2)
+#undef TRV_EXCHANGE
+                p0 = s3 < rt_inf(); p1 = s2 < rt_inf(); p2 = s1 < rt_inf();
+            } else {
+                // the first place to be visited next, every later one stacked
+                t0 = g0 ? r0 : (g1 ? r1 : (g2 ? r2 : r3));
+                p2 = g1 && g0;
+                p1 = g2 && (g0 || g1);
+                p0 = g3 && (g0 || g1 || g2);
+            }
             const uint32_t bestRef = t0;
-            const bool p0 = s3 < rt_inf(), p1 = s2 < rt_inf(), p2 = s1 < rt_inf();
             if (__builtin_expect(w.sp + 2u < TRV_STACK_LDS, 1)) {    // levels sp .. sp + 2 are all LDS levels
                 stk[w.sp * TRV_THREADS] = t3;
                 w.sp += p0 ? 1u : 0u;
@@ -718,17 +731,31 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
             const uint32_t oct = uniform ? ((sx ? 1u : 0u) | (sy ? 2u : 0u) | (sz ? 4u : 0u)) : 8u;
             constexpr bool NEAR = true;                              // every kind of ray gains: a hit found sooner, or a closer one
             const float limit = h.t * sv.pruneScale;                 // +inf without a hit, or with the option off
-            if (sv.wnodes != nullptr) {
+            // front to back, with the boxes beyond `limit` left out, where that can end a walk sooner; as the boxes come otherwise
+            const bool ordered = COUNT || Src::FIRST_HIT_MAY_DECIDE || sv.pruneScale < rt_inf();
+            if (sv.wnodes != nullptr && ordered) {
                 switch (oct) {
-                case 0: node_phase_wide<0, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
-                case 1: node_phase_wide<1, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
-                case 2: node_phase_wide<2, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
-                case 3: node_phase_wide<3, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
-                case 4: node_phase_wide<4, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
-                case 5: node_phase_wide<5, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
-                case 6: node_phase_wide<6, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
-                case 7: node_phase_wide<7, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
-                default: node_phase_wide<8, COUNT>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 0: node_phase_wide<0, COUNT, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 1: node_phase_wide<1, COUNT, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 2: node_phase_wide<2, COUNT, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 3: node_phase_wide<3, COUNT, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 4: node_phase_wide<4, COUNT, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 5: node_phase_wide<5, COUNT, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 6: node_phase_wide<6, COUNT, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 7: node_phase_wide<7, COUNT, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                default: node_phase_wide<8, COUNT, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                }
+            } else if (!COUNT && !Src::FIRST_HIT_MAY_DECIDE && sv.wnodes != nullptr) {
+                switch (oct) {
+                case 0: node_phase_wide<0, false, false>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 1: node_phase_wide<1, false, false>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 2: node_phase_wide<2, false, false>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 3: node_phase_wide<3, false, false>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 4: node_phase_wide<4, false, false>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 5: node_phase_wide<5, false, false>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 6: node_phase_wide<6, false, false>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                case 7: node_phase_wide<7, false, false>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
+                default: node_phase_wide<8, false, false>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
                 }
             } else
             switch (oct) {
