@@ -386,22 +386,38 @@ def main():
     # Dispatch(CSMain), Dispatch(ShadowMap), Blit(addMaterial) -- one frame in flight, nothing shared between passes.
     dropin_frames = 0 if args.no_dropin else min(args.spp, 16)
     dropin_ms = None
+    dropin_readback_ms = {}
     if dropin_frames:
         use_shadow = bool(params.flags & wire.FLAG_MATTE_MASK)
-        for timed in (False, True):
-            core.set_dirty()
-            core.synchronize()
-            t1 = time.perf_counter()
-            for k in range(dropin_frames):
-                params.seed = float(seeds[k])
-                core.set_params(params)
-                core.dispatch()
-                if use_shadow:
-                    core.dispatch_shadowmap()
-                core.accumulate(k, use_shadow)
-            core.synchronize()
-            if timed:
-                dropin_ms = (time.perf_counter() - t1) / dropin_frames * 1e3
+        pinned = torch.empty((args.height, args.width, 4), dtype=torch.float32).pin_memory()
+        host_frame = np.empty((args.height, args.width, 4), np.float32)
+        # without a readback, with the blocking rt_readback of every frame (what Unity's ReadPixels would be), and with
+        # rt_readback_async into page-locked memory, which leaves while the next frame is traced
+        for readback in (None, "blocking", "async"):
+            for timed in (False, True):
+                core.set_dirty()
+                core.synchronize()
+                t1 = time.perf_counter()
+                for k in range(dropin_frames):
+                    params.seed = float(seeds[k])
+                    core.set_params(params)
+                    core.dispatch()
+                    if use_shadow:
+                        core.dispatch_shadowmap()
+                    core.accumulate(k, use_shadow)
+                    if readback == "blocking":
+                        core.readback_into(wire.IMAGE_CONVERGED, host_frame)
+                    elif readback == "async":
+                        core.readback_async(wire.IMAGE_CONVERGED, pinned.data_ptr())
+                if readback == "async":
+                    core.readback_wait()
+                core.synchronize()
+                if timed:
+                    ms = (time.perf_counter() - t1) / dropin_frames * 1e3
+                    if readback is None:
+                        dropin_ms = ms
+                    else:
+                        dropin_readback_ms[readback] = round(ms, 4)
 
     # ---- roofline pass (untimed by the wall clock): the same step with every launch bracketed by HIP events
     # on the library's stream.  With the events on, the library keeps its launches in the plain order (the
@@ -498,6 +514,7 @@ def main():
             "ms_per_image": round(ms_per_step, 3),
             "per_frame_dropin": None if dropin_ms is None else {
                 "ms_per_frame_1spp": round(dropin_ms, 4), "frames": dropin_frames,
+                "ms_per_frame_with_a_full_frame_readback": dropin_readback_ms,
                 "sequence": "rt_set_params(seed) + rt_dispatch + rt_dispatch_shadowmap + rt_accumulate per frame (RayTracing.cs:118-164), "
                             "one frame in flight"},
             "paths_per_step": args.width * args.height * args.spp,

@@ -141,6 +141,11 @@ public static class RtCoreNative
     // rt_local_pixel_map says which pixel each tile-local slot is.
     [DllImport(Lib)] public static extern int rt_readback_merge(IntPtr ctx, int which, Color[] frameRgba);
     [DllImport(Lib)] public static extern int rt_readback_local_device(IntPtr ctx, int which, IntPtr deviceDst);
+    // the same merge into a frame that stays in device memory (of this context's device or another one): no host hop
+    [DllImport(Lib)] public static extern int rt_merge_local_device(IntPtr ctx, int which, IntPtr deviceFrameRgba, int frameDevice);
+    // rt_readback in the background into page-locked memory (a pinned GCHandle's address); complete after rt_readback_wait
+    [DllImport(Lib)] public static extern int rt_readback_async(IntPtr ctx, int which, IntPtr pinnedDstRgba);
+    [DllImport(Lib)] public static extern int rt_readback_wait(IntPtr ctx);
     [DllImport(Lib)] public static extern uint rt_local_pixel_count(IntPtr ctx);
     [DllImport(Lib)] public static extern int rt_local_pixel_map(IntPtr ctx, uint[] dst);
 
@@ -194,5 +199,24 @@ public static class RtCoreNative
         }
         for (int i = 0; i < contexts.Length; ++i) { threads[i].Join(); Check(contexts[i], codes[i]); }
         for (int i = 0; i < contexts.Length; ++i) Check(contexts[i], rt_readback_merge(contexts[i], RT_IMAGE_CONVERGED, frame));
+    }
+
+    // The same with the frame kept on a GPU: every context writes its tiles into `deviceFrame` (width*height float4 in the
+    // memory of device `frameDevice`, e.g. the one that presents or post-processes), device to device.
+    public static void RenderSplitFrameOnDevice(IntPtr[] contexts, float[] seeds, IntPtr deviceFrame, int frameDevice)
+    {
+        var threads = new System.Threading.Thread[contexts.Length];
+        var codes = new int[contexts.Length];
+        for (int i = 0; i < contexts.Length; ++i)
+        {
+            int k = i;
+            threads[k] = new System.Threading.Thread(() =>
+            {
+                codes[k] = rt_render_frames(contexts[k], seeds, (uint)seeds.Length);
+                if (codes[k] == RT_OK) codes[k] = rt_merge_local_device(contexts[k], RT_IMAGE_CONVERGED, deviceFrame, frameDevice);
+            });
+            threads[k].Start();
+        }
+        for (int i = 0; i < contexts.Length; ++i) { threads[i].Join(); Check(contexts[i], codes[i]); }
     }
 }

@@ -286,6 +286,21 @@ int rt_readback(RtContext *ctx, int which, float *dst_rgba);
  * write disjoint pixels, so the calls may run from different threads.
  * RT_IMAGE_RT / RT_IMAGE_CONVERGED / RT_IMAGE_SHADOWMAP only. */
 int rt_readback_merge(RtContext *ctx, int which, float *frame_rgba);
+/* rt_readback in the background, for a host that keeps rendering: the image is staged on the device when the call is
+ * made (the library may render into it again as soon as the call returns) and copied to `pinned_dst_rgba` -- page-locked
+ * host memory of the caller, width*height*4 floats, e.g. a pinned GCHandle / hipHostMalloc -- by a copy stream while the
+ * next frames are traced.  The destination is complete after rt_readback_wait (also the place the traversal error flag is
+ * reported); a second rt_readback_async waits for the first one's copy by itself.  The reference reads its render
+ * textures back with a blocking ReadPixels (SaveTexture.cs:59-70); RT_IMAGE_RT / RT_IMAGE_CONVERGED / RT_IMAGE_SHADOWMAP only. */
+int rt_readback_async(RtContext *ctx, int which, float *pinned_dst_rgba);
+int rt_readback_wait(RtContext *ctx);
+/* rt_readback_merge without the host: this context's tiles are written INTO a full frame (width*height float4, row 0 =
+ * bottom) that lives in DEVICE memory of `frame_device`, this context's own device or another one of the process; every
+ * other pixel keeps its value, so the contexts that split a frame (RayTracing.cs:365-370 blits ONE frame) merge into one
+ * device buffer, one call each, without the frame crossing to the host.  Across devices the tiles are written through the
+ * peer mapping where the devices allow it (over xGMI), otherwise copied as they are and placed by the frame's device.
+ * The across-device paths have not run on hardware (no multi-GPU box in reach of this build). */
+int rt_merge_local_device(RtContext *ctx, int which, void *device_frame_rgba, int frame_device);
 /* Same image, but only this rank's tiles in tile-local order, copied to a
  * DEVICE pointer (e.g. a torch tensor) of rt_local_pixel_count()*4 floats, for
  * gathering over RCCL without a host hop. */
@@ -310,8 +325,9 @@ int rt_trace_rays_device(RtContext *ctx, const void *device_origins4, const void
                          uint32_t n, void *device_hits4);
 
 /* rt_trace_rays_device without any allocation.  No counterpart in the reference: it is for
- * callers that cannot allocate device memory -- code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc.  The walker's scratch (ray cursor, overflow flag,
+ * callers that cannot allocate device memory -- tight serving loops, harnesses that forbid
+ * hipMalloc.  (It is not a call to put under HIP graph capture as it stands: it works on the
+ * context's own stream and waits for that stream to report a stack overflow.)  The walker's scratch (ray cursor, overflow flag,
  * the stack levels a lane spills) lives in a static device array of 20 MB that every GPU the
  * library runs on holds until the process ends, instead of buffers of the context; the call
  * makes no hipMalloc / hipFree, creates no events and keeps no timing.  Same inputs, outputs

@@ -155,7 +155,14 @@ int rt_destroy(RtContext *ctx)
 {
     if (!ctx) return RT_OK;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    // nothing may still run when the buffers go: a ShadowMap pass that rt_dispatch started walks its rays on the masked
+    // stream shared with other contexts; the main stream is made to wait for it, then drained
+    if (ctx->stream) {
+        (void)rt_eager_cancel(ctx);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (ctx->streamShadow) (void)hipStreamSynchronize(ctx->streamShadow);
+    if (ctx->streamChain) (void)hipStreamSynchronize(ctx->streamChain);
     rt_timer_resolve(ctx);
     for (hipEvent_t e : ctx->eventPool) (void)hipEventDestroy(e);
     rt_free_build(ctx);
@@ -166,6 +173,13 @@ int rt_destroy(RtContext *ctx)
                     ctx->dDisc, ctx->dCube, ctx->dStats, ctx->dErrorFlag, ctx->dQCount, ctx->dStackSpill, ctx->dNonCasters};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (ctx->streamCopy) {
+        (void)hipStreamSynchronize(ctx->streamCopy);
+        (void)hipStreamDestroy(ctx->streamCopy);
+        (void)hipEventDestroy(ctx->evExpanded);
+        (void)hipEventDestroy(ctx->evCopied);
+    }
+    if (ctx->dReadbackFull) (void)hipFree(ctx->dReadbackFull);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2), (void)hipStreamDestroy(ctx->stream2);
     rt_release_overlap_streams(ctx);
     if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
@@ -472,6 +486,100 @@ int rt_readback_merge(RtContext *ctx, int which, float *frame_rgba)
     }
     rt_timer_resolve(ctx);
     return check_error_flag(ctx);
+}
+
+/* The frame leaves in the background: the tiles are expanded into a full frame in device memory on the context's stream
+ * (so the images are free to be rendered into again as soon as the call returns), and a copy stream takes that frame to
+ * the caller's memory while the next frames are rendered. */
+int rt_readback_async(RtContext *ctx, int which, float *pinned_dst_rgba)
+{
+    RT_ENTER(ctx);
+    if (!pinned_dst_rgba) return rt_fail(ctx, RT_E_INVALID, "null destination");
+    if (!ctx->paramsSet) return rt_fail(ctx, RT_E_STATE, "rt_set_params has not been called");
+    if (which != RT_IMAGE_RT && which != RT_IMAGE_CONVERGED && which != RT_IMAGE_SHADOWMAP)
+        return rt_fail(ctx, RT_E_INVALID, "rt_readback_async: RT_IMAGE_RT / _CONVERGED / _SHADOWMAP only");
+    float4 *src = rt_image_ptr(ctx, which);
+    if (!src) return rt_fail(ctx, RT_E_INVALID, "bad image selector %d", which);
+    const size_t px = (size_t)ctx->params.width * ctx->params.height;
+    if (!ctx->streamCopy) {
+        RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->streamCopy, hipStreamNonBlocking));
+        RT_HIP(ctx, hipEventCreateWithFlags(&ctx->evExpanded, hipEventDisableTiming));
+        RT_HIP(ctx, hipEventCreateWithFlags(&ctx->evCopied, hipEventDisableTiming));
+    }
+    if (ctx->copyPending) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evCopied, 0));   // the staging frame is still being read
+    if (ctx->readbackPixels != px) {
+        if (ctx->copyPending) RT_HIP(ctx, hipEventSynchronize(ctx->evCopied));
+        if (ctx->dReadbackFull) (void)hipFree(ctx->dReadbackFull);
+        ctx->dReadbackFull = nullptr;
+        ctx->readbackPixels = 0;
+        RT_HIP(ctx, hipMalloc((void **)&ctx->dReadbackFull, (px ? px : 1) * sizeof(float4)));
+        ctx->readbackPixels = px;
+    }
+    if (ctx->tile.count > 1) RT_HIP(ctx, hipMemsetAsync(ctx->dReadbackFull, 0, px * sizeof(float4), ctx->stream));   // other ranks' pixels read 0
+    int rc = rt_expand_local_impl(ctx, src, ctx->dReadbackFull);
+    if (rc) return rc;
+    RT_HIP(ctx, hipEventRecord(ctx->evExpanded, ctx->stream));
+    RT_HIP(ctx, hipStreamWaitEvent(ctx->streamCopy, ctx->evExpanded, 0));
+    RT_HIP(ctx, hipMemcpyAsync(pinned_dst_rgba, ctx->dReadbackFull, px * sizeof(float4), hipMemcpyDeviceToHost, ctx->streamCopy));
+    RT_HIP(ctx, hipEventRecord(ctx->evCopied, ctx->streamCopy));
+    ctx->copyPending = true;
+    return RT_OK;
+}
+
+int rt_readback_wait(RtContext *ctx)
+{
+    RT_ENTER(ctx);
+    if (!ctx->copyPending) return RT_OK;
+    RT_HIP(ctx, hipEventSynchronize(ctx->evCopied));
+    ctx->copyPending = false;
+    return check_error_flag(ctx);
+}
+
+/* This context's tiles into a full frame that already lives in device memory, on this context's device or on another
+ * one of the process: the device-side form of rt_readback_merge.  The frame's device writes the pixels where this
+ * device cannot reach its memory. */
+int rt_merge_local_device(RtContext *ctx, int which, void *device_frame_rgba, int frame_device)
+{
+    RT_ENTER(ctx);
+    if (!ctx->paramsSet) return rt_fail(ctx, RT_E_STATE, "rt_set_params has not been called");
+    float4 *src = rt_image_ptr(ctx, which);
+    if (!src || !device_frame_rgba) return rt_fail(ctx, RT_E_INVALID, "bad image selector or null destination");
+    if (which != RT_IMAGE_RT && which != RT_IMAGE_CONVERGED && which != RT_IMAGE_SHADOWMAP)
+        return rt_fail(ctx, RT_E_INVALID, "rt_merge_local_device: RT_IMAGE_RT / _CONVERGED / _SHADOWMAP only");
+    int nDev = 0;
+    RT_HIP(ctx, hipGetDeviceCount(&nDev));
+    if (frame_device < 0 || frame_device >= nDev) return rt_fail(ctx, RT_E_INVALID, "frame_device %d out of range", frame_device);
+    if (frame_device != ctx->device) {
+        int can = 0;
+        RT_HIP(ctx, hipDeviceCanAccessPeer(&can, ctx->device, frame_device));
+        if (can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(frame_device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
+            (void)hipGetLastError();
+        }
+        if (!can) {
+            // no direct path: the tiles travel as they are (one contiguous copy) and the frame's own device places them
+            const size_t bytes = (size_t)ctx->tile.nSlots * sizeof(float4);
+            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            float4 *staged = nullptr;
+            RT_HIP(ctx, hipSetDevice(frame_device));
+            hipError_t e = hipMalloc((void **)&staged, bytes ? bytes : 16);
+            if (e == hipSuccess) e = hipMemcpyPeer(staged, frame_device, src, ctx->device, bytes);
+            int rc = RT_OK;
+            if (e == hipSuccess) {
+                rc = rt_expand_local_on(ctx, nullptr, staged, (float4 *)device_frame_rgba);
+                if (rc == RT_OK) e = hipDeviceSynchronize();
+            }
+            if (staged) (void)hipFree(staged);
+            (void)hipSetDevice(ctx->device);
+            if (e != hipSuccess) return rt_fail(ctx, RT_E_DEVICE, "rt_merge_local_device: staging on device %d failed: %s", frame_device, hipGetErrorString(e));
+            return rc;
+        }
+    }
+    int rc = rt_expand_local_impl(ctx, src, (float4 *)device_frame_rgba);      // writes this context's pixels only
+    if (rc) return rc;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
 }
 
 int rt_readback_local_device(RtContext *ctx, int which, void *device_dst)

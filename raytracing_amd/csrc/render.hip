@@ -760,6 +760,9 @@ static int alloc_batch(RtContext *ctx, uint32_t frames)
 {
     const uint32_t n = ctx->tile.nSlots;
     if (frames <= ctx->batchCap) return RT_OK;
+    // a ShadowMap pass that rt_dispatch started may still be walking its rays on the masked stream, out of the buffers that go now
+    int rc = rt_eager_cancel(ctx);
+    if (rc) return rc;
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     void **ptrs[] = {(void **)&ctx->dRt, (void **)&ctx->dShadowMap, (void **)&ctx->dPe,
                      (void **)&ctx->dRng, (void **)&ctx->dHit, (void **)&ctx->dRay[0], (void **)&ctx->dRay[1],
@@ -1342,12 +1345,12 @@ int rt_trace_device_impl(RtContext *ctx, const float4 *o, const float4 *d, uint3
 // ---- first-hit queries that allocate nothing
 // The walker's scratch -- the ray cursor, the overflow flag and the per-lane spill levels of the stack -- in a
 // file-scope array instead of buffers the context allocates, for callers that may not allocate device memory
-// (code under HIP graph capture, tight serving loops).  Every GPU the library runs on holds one copy of the
+// (tight serving loops, harnesses that forbid hipMalloc).  Every GPU the library runs on holds one copy of the
 // array until the process ends; all calls on a GPU share it, so calls that overlap on one GPU race.
 //   words 0..31   the ray cursor's line          (cleared by every call)
 //   words 32..63  the overflow flag's line       (cleared by every call)
 //   from word 64  RT_STATIC_BLOCKS x TRV_THREADS lanes x (RT_STACK_DEPTH - TRV_STACK_LDS) stack levels (written before read)
-#define RT_STATIC_BLOCKS 1280u                                     // five resident blocks on each of 256 compute units
+#define RT_STATIC_BLOCKS 1280u                                     // five blocks on each of 256 compute units, one fewer than are resident at a time: the array stays at 20 MB
 #define RT_STATIC_HEAD_WORDS 64u
 #define RT_STATIC_SPILL_WORDS (RT_STATIC_BLOCKS * TRV_THREADS * (RT_STACK_DEPTH - TRV_STACK_LDS))
 static __device__ __align__(256) uint32_t scratch[RT_STATIC_HEAD_WORDS + RT_STATIC_SPILL_WORDS];   // 20 MB
@@ -1420,14 +1423,16 @@ int rt_trace_primitives_impl(RtContext *ctx, const float4 *o, const float4 *d, u
     return RT_OK;
 }
 
-int rt_expand_local_impl(RtContext *ctx, const float4 *local, float4 *full)
+int rt_expand_local_on(RtContext *ctx, hipStream_t stream, const float4 *local, float4 *full)
 {
     const uint32_t n = ctx->tile.nSlots;
     if (n == 0) return RT_OK;
-    hipLaunchKernelGGL(k_expand_local, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->tile, local, full);
+    hipLaunchKernelGGL(k_expand_local, dim3((n + 255) / 256), dim3(256), 0, stream, ctx->tile, local, full);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
 }
+
+int rt_expand_local_impl(RtContext *ctx, const float4 *local, float4 *full) { return rt_expand_local_on(ctx, ctx->stream, local, full); }
 
 int rt_hits_to_host_impl(RtContext *ctx, const RtHitRec *hits, uint32_t n, float *t, uint32_t *tri, float *u, float *v)
 {

@@ -300,6 +300,13 @@ struct RtContext {
     std::vector<RtPendingEvent> pending;
     std::vector<hipEvent_t> eventPool;
 
+    // rt_readback_async: a full frame in device memory that the tiles are expanded into, and the stream that copies it out
+    float4 *dReadbackFull = nullptr;
+    size_t readbackPixels = 0;
+    hipStream_t streamCopy = nullptr;
+    hipEvent_t evExpanded = nullptr, evCopied = nullptr;
+    bool copyPending = false;
+
     RtPostState *post = nullptr;          // images and scratch of the post-process chain, made on first use
 };
 
@@ -380,6 +387,7 @@ int rt_trace_device_impl(RtContext *ctx, const float4 *o, const float4 *d, uint3
 int rt_static_scratch_init(RtContext *ctx);   // once per device, from rt_create
 int rt_trace_device_static_impl(RtContext *ctx, const float4 *o, const float4 *d, uint32_t n, RtHitRec *hits);
 int rt_expand_local_impl(RtContext *ctx, const float4 *local, float4 *full);
+int rt_expand_local_on(RtContext *ctx, hipStream_t stream, const float4 *local, float4 *full);   // the same scatter on another stream (of any device that sees both buffers)
 int rt_trace_primitives_impl(RtContext *ctx, const float4 *o, const float4 *d, uint32_t n, float *t, uint32_t *prim, float *normal3);
 int rt_pack_rays_impl(RtContext *ctx, const float *o3, const float *d3, uint32_t n, float4 *o4, float4 *d4);
 int rt_debug_eval_impl(RtContext *ctx, int which, const float *dx, const float *dy, uint32_t n, float *dout);

@@ -24,7 +24,8 @@ EXPORTS = [
     "rt_kernel_time", "rt_synchronize", "rt_version", "rt_debug_eval", "rt_set_option",
     "rt_image_upload", "rt_image_size", "rt_post_blit", "rt_post_color_correction", "rt_post_lut_upload",
     "rt_post_color_grading", "rt_post_bloom", "rt_save_rgb24", "rt_primitives_upload", "rt_trace_primitives",
-    "rt_readback_walk_tree", "rt_trace_rays_device_static", "rt_readback_merge",
+    "rt_readback_walk_tree", "rt_trace_rays_device_static", "rt_readback_merge", "rt_merge_local_device",
+    "rt_readback_async", "rt_readback_wait",
 ]
 
 _lib = None
@@ -82,6 +83,7 @@ class RtCore:
             raise RtError(rc, "rt_create failed (no usable HIP device?)")
         self.n_triangles = 0
         self.params = None
+        self.device_id = device_id
 
     def _check(self, rc):
         if rc != 0:
@@ -223,6 +225,24 @@ class RtCore:
         if frame.dtype != np.float32 or not frame.flags.c_contiguous or frame.shape != (self.params.height, self.params.width, 4):
             raise ValueError("frame must be a C-contiguous float32 array of shape (height, width, 4)")
         self._check(self.lib.rt_readback_merge(self.ctx, C.c_int(which), _p(frame)))
+
+    def readback_into(self, which, frame):
+        """rt_readback into a float32 array the caller already holds (height x width x 4)."""
+        if frame.dtype != np.float32 or not frame.flags["C_CONTIGUOUS"] or frame.size != self.params.width * self.params.height * 4:
+            raise ValueError("frame must be a C-contiguous float32 array of height x width x 4")
+        self._check(self.lib.rt_readback(self.ctx, C.c_int(which), _p(frame)))
+
+    def merge_local_device(self, which, device_frame_ptr, frame_device=None):
+        """This context's tiles into a full float4 frame in device memory (of `frame_device`, default: this context's)."""
+        dev = self.device_id if frame_device is None else frame_device
+        self._check(self.lib.rt_merge_local_device(self.ctx, C.c_int(which), C.c_void_p(device_frame_ptr), C.c_int(dev)))
+
+    def readback_async(self, which, pinned_host_ptr):
+        """Full-frame readback in the background into page-locked host memory; complete after readback_wait()."""
+        self._check(self.lib.rt_readback_async(self.ctx, C.c_int(which), C.c_void_p(pinned_host_ptr)))
+
+    def readback_wait(self):
+        self._check(self.lib.rt_readback_wait(self.ctx))
 
     def readback_local_device(self, which, device_ptr):
         self._check(self.lib.rt_readback_local_device(self.ctx, C.c_int(which), C.c_void_p(device_ptr)))

@@ -153,6 +153,48 @@ def test_first_hit_bit_exact(core, oracle, name, packets):
         assert hit.sum() > 100
 
 
+def test_first_hit_bit_exact_on_the_full_car(core, oracle):
+    """The bench scene at full detail (495 842 triangles): camera rays, rays from the car's surfaces towards the light
+    (what the soft-shadow rays are) and rays between random points of its box, against the checker's walk of the
+    reference's tree; work counters of the default walker against the checker's restatement of it."""
+    sc = scenes.car_standin(64, 64, detail=1.0)
+    orc = oracle.Oracle(sc).build()
+    core.upload(sc)
+    core.bvh_build()
+    o1, d1 = H.camera_rays(sc.params, 48)
+    first = orc.trace(o1, d1)
+    hit = first["triangle"] != 0xFFFFFFFF
+    assert hit.sum() > 500
+    rs = np.random.Generator(np.random.PCG64(77))
+    light = -np.array(sc.params.lightParameter[:3], np.float64)
+    o2 = (o1[hit].astype(np.float64) + d1[hit].astype(np.float64) * (first["t"][hit, None] - 1e-3)).astype(np.float32)
+    d2 = light[None, :] + rs.normal(scale=0.1, size=(len(o2), 3))
+    d2 = (d2 / np.linalg.norm(d2, axis=1, keepdims=True)).astype(np.float32)
+    v = np.asarray(sc.vertices["position"], np.float32).reshape(-1, 3)
+    lo, hi = v.min(axis=0), v.max(axis=0)
+    lo[1] = max(lo[1], 0.0)
+    a = (lo + (hi - lo) * rs.random((3000, 3))).astype(np.float32)
+    b = (lo + (hi - lo) * rs.random((3000, 3))).astype(np.float32)
+    d3 = b - a
+    d3 /= np.linalg.norm(d3, axis=1, keepdims=True)
+    o = np.concatenate([o1, o2, a])
+    d = np.concatenate([d1, d2, d3.astype(np.float32)])
+    want = orc.trace(o, d)
+    core.enable_counters(True)
+    core.reset_stats()
+    got = core.trace_rays(o, d)
+    st = core.stats()
+    core.enable_counters(False)
+    plain = core.trace_rays(o, d)
+    for k in ("triangle", "t", "u", "v"):
+        H.assert_bits_equal(got[k], want[k], f"{k}: counting kernel vs the reference's walk")
+        H.assert_bits_equal(plain[k], want[k], f"{k}: plain kernel vs the reference's walk")
+    want_counters = orc.trace(o, d, wide=True)["counters"]
+    for k in ("rays", "internalVisits", "leafVisits", "triTests", "hits"):
+        assert st[k] == want_counters[k], f"counter {k}: gpu {st[k]} vs checker {want_counters[k]}"
+    assert (want["triangle"] != 0xFFFFFFFF).sum() > 2000
+
+
 @pytest.mark.parametrize("sampling", [wire.SAMPLING_MIS, wire.SAMPLING_BSDF, wire.SAMPLING_LIGHT, wire.SAMPLING_COSINE,
                                       wire.SAMPLING_UNIFORM])
 def test_cornell_radiance(core, oracle, sampling):
@@ -554,6 +596,34 @@ def test_two_live_contexts_split_one_frame(core):
             c.readback_local_device(wire.IMAGE_CONVERGED, buf.data_ptr())
         torch.cuda.synchronize()
         H.assert_bits_equal(g.place().cpu().numpy(), whole, "TileGatherer.place of two contexts")
+        # the C ABI's own device-side merge: both contexts write their tiles into ONE frame in device memory
+        frame = torch.full((sc.params.height, sc.params.width, 4), -1.0, dtype=torch.float32, device="cuda:0")
+        frame_shadow = torch.full_like(frame, -1.0)
+        torch.cuda.synchronize()
+        parts[0].merge_local_device(wire.IMAGE_CONVERGED, frame.data_ptr())
+        torch.cuda.synchronize()
+        one = frame.cpu().numpy()
+        assert (one[~own] == -1).all() and np.array_equal(one[own].view(np.uint32), whole[own].view(np.uint32))
+        parts[1].merge_local_device(wire.IMAGE_CONVERGED, frame.data_ptr(), 0)
+        for c in parts:
+            c.merge_local_device(wire.IMAGE_SHADOWMAP, frame_shadow.data_ptr())
+        torch.cuda.synchronize()
+        H.assert_bits_equal(frame.cpu().numpy(), merged, "rt_merge_local_device of two contexts vs rt_readback_merge")
+        H.assert_bits_equal(frame_shadow.cpu().numpy(), merged_shadow, "rt_merge_local_device of two contexts (shadow map)")
+        with pytest.raises(native.RtError):
+            parts[0].merge_local_device(wire.IMAGE_CONVERGED, frame.data_ptr(), 99)        # no such device
+        # rt_readback in the background into page-locked memory
+        pinned = torch.empty((sc.params.height, sc.params.width, 4), dtype=torch.float32).pin_memory()
+        pinned.fill_(-3.0)
+        core.readback_async(wire.IMAGE_CONVERGED, pinned.data_ptr())
+        core.set_dirty()
+        core.render_frames(seeds[:1])                       # the next frame is rendered while the copy runs
+        core.readback_wait()
+        H.assert_bits_equal(pinned.numpy(), whole, "rt_readback_async")
+        part_pinned = torch.empty_like(pinned).pin_memory()
+        parts[1].readback_async(wire.IMAGE_CONVERGED, part_pinned.data_ptr())
+        parts[1].readback_wait()
+        H.assert_bits_equal(part_pinned.numpy(), parts[1].readback(wire.IMAGE_CONVERGED), "rt_readback_async of a tile share")
     finally:
         for c in parts:
             c.close()

@@ -23,7 +23,10 @@ def _both(torch, core, o, d):
     got = torch.full((n, 4), -2.0, dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
     core.trace_rays_device(o4.data_ptr(), d4.data_ptr(), n, want.data_ptr())
+    core.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]            # hipMemGetInfo: free device memory
     core.trace_rays_device_static(o4.data_ptr(), d4.data_ptr(), n, got.data_ptr())
+    assert torch.cuda.mem_get_info()[0] == free_before, "the call must not allocate or free device memory"
     return want.cpu().numpy(), got.cpu().numpy()
 
 
