@@ -151,6 +151,13 @@ class Oracle:
             return img, dict(zip(("rays", "internalVisits", "leafVisits", "triTests", "hits"), map(int, cnt)))
         return img
 
+    def render_region(self, params, x0, y0, w, h, shadow=False):
+        """One CSMain frame (and the ShadowMap kernel's) for the w x h pixels at (x0, y0) of the frame `params` describes."""
+        img = np.zeros((h, w, 4), np.float32)
+        sm = np.zeros((h, w, 4), np.float32) if shadow else None
+        lib().orc_render_region(self.h, C.byref(params), C.c_int(x0), C.c_int(y0), C.c_int(w), C.c_int(h), _p(img), _p(sm))
+        return (img, sm) if shadow else img
+
     def shadowmap(self, params, counters=False):
         img = np.zeros((params.height, params.width, 4), np.float32)
         if counters:
@@ -177,6 +184,20 @@ def render_frames(oracle, params, seeds, use_shadow=False):
         p.seed = float(s)
         rt = oracle.render(p)
         sm = oracle.shadowmap(p) if use_shadow else None
+        accumulate(conv, rt, sm, k, use_shadow)
+    return conv
+
+
+def render_frames_region(oracle, params, seeds, x0, y0, w, h, use_shadow=False):
+    """render_frames for a rectangle of the frame only: the running mean of its pixels."""
+    conv = np.zeros((h, w, 4), np.float32)
+    p = params.copy()
+    for k, s in enumerate(seeds):
+        p.seed = float(s)
+        if use_shadow:
+            rt, sm = oracle.render_region(p, x0, y0, w, h, shadow=True)
+        else:
+            rt, sm = oracle.render_region(p, x0, y0, w, h), None
         accumulate(conv, rt, sm, k, use_shadow)
     return conv
 

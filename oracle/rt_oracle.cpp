@@ -1803,6 +1803,19 @@ void orc_render(void *h, const RtParams *P, float *dst, uint64_t *counters)
     }
 }
 
+// CSMain (and, shadow != NULL, the ShadowMap kernel) for the pixels of a rectangle of the frame only: dst / shadow =
+// w*h*4 floats, row 0 = id.y y0.  Pixel coordinates stay the frame's, so the values are those of the whole-frame run.
+void orc_render_region(void *h, const RtParams *P, int x0, int y0, int w, int hgt, float *dst, float *shadow)
+{
+    const Scene &s = *(Scene *)h;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int y = 0; y < hgt; ++y)
+        for (int x = 0; x < w; ++x) {
+            CSMain(s, *P, (uint32_t)(x0 + x), (uint32_t)(y0 + y), dst + ((size_t)y * w + x) * 4, nullptr);
+            if (shadow) ShadowMapKernel(s, *P, (uint32_t)(x0 + x), (uint32_t)(y0 + y), shadow + ((size_t)y * w + x) * 4, nullptr);
+        }
+}
+
 void orc_shadowmap(void *h, const RtParams *P, float *dst)
 {
     const Scene &s = *(Scene *)h;

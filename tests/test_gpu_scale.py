@@ -307,6 +307,53 @@ def test_config4_car_4k_eight_tile_sets_make_the_whole_frame(core):
     assert covered.all()
 
 
+@pytest.mark.parametrize("config", ["cornell 1080p + ShadowMap", "pbr grid 1080p", "car 4K + DoF + ShadowMap", "car 1080p + DoF + ShadowMap"])
+def test_full_size_frames_against_the_checker_on_crops(core, oracle, config):
+    """The named configurations at their full size, two frames accumulated, held to the CPU checker where the checker
+    can follow: on 40 x 40-pixel crops of the frame (a pixel depends on its own coordinates, the seed and the scene only,
+    so the checker renders just those pixels with the frame's own parameters).  Same bits."""
+    if config.startswith("cornell"):
+        sc = scenes.cornell_box(1920, 1080)
+        p = sc.params.copy()
+        p.flags |= wire.FLAG_MATTE_MASK
+        p.lightParameter[3] = 0.1
+        p.shadowParameter[3] = 1.0
+        crops = [(940, 300), (400, 700), (1500, 120)]
+    elif config.startswith("pbr"):
+        sc = scenes.pbr_sphere_grid(1920, 1080)
+        p = sc.params.copy()
+        crops = [(940, 520), (300, 300), (1400, 700)]
+    elif config.startswith("car 4K"):
+        sc = scenes.car_standin(3840, 2160)
+        p = sc.params.copy()
+        crops = [(1900, 1000), (1200, 700), (2600, 1300), (100, 2000)]
+    else:
+        sc = scenes.car_standin(1920, 1080)
+        p = sc.params.copy()
+        crops = [(950, 500), (600, 380), (1300, 640)]
+    use_shadow = bool(p.flags & wire.FLAG_MATTE_MASK)
+    seeds = scenes.frame_seeds(2, seed=21)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(p)
+    core.set_dirty()
+    core.render_frames(seeds)
+    got = core.readback(wire.IMAGE_CONVERGED)
+    got_sm = core.readback(wire.IMAGE_SHADOWMAP) if use_shadow else None
+    orc = oracle.Oracle(sc).build()
+    lit = 0
+    for x0, y0 in crops:
+        want = oracle.render_frames_region(orc, p, seeds, x0, y0, 40, 40, use_shadow=use_shadow)
+        H.assert_bits_equal(got[y0:y0 + 40, x0:x0 + 40], want, f"{config}: converged image at ({x0}, {y0})")
+        lit += int((want[..., :3] > 0).any(-1).sum())
+        if use_shadow:
+            pl = p.copy()
+            pl.seed = float(seeds[-1])
+            _, sm = orc.render_region(pl, x0, y0, 40, 40, shadow=True)
+            H.assert_bits_equal(got_sm[y0:y0 + 40, x0:x0 + 40], sm, f"{config}: shadow map of the last frame at ({x0}, {y0})")
+    assert lit > 1000
+
+
 def test_car_1080p_execution_options_do_not_change_a_bit(core):
     """The bench workload at full size, 16 frames in flight: shadow rays that end at their first hit, the ShadowMap
     pass walked while the later bounces run on masked streams, material-sorted shading, boxes beyond the closest hit

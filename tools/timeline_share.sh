@@ -1,0 +1,11 @@
+#!/bin/bash
+# Kernel timeline of one rank's share of the bench frame: tools/timeline_share.sh <out_dir> <world>   (GPU box, repository root)
+set -u
+OUT=$1; W=$2
+export TMPDIR=/tmp REPS=1
+mkdir -p "$OUT"
+timeout -s KILL 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -o t -- python3 tools/rank_share.py "$W" > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
+CSV=$(find "$OUT/trace" -name '*kernel_trace.csv' | head -1)
+python3 tools/timeline.py "$CSV" > "$OUT/timeline.txt"
+tail -1 "$OUT/trace.log" >> "$OUT/timeline.txt"
+rm -rf "$OUT/trace"
