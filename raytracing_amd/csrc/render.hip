@@ -333,7 +333,9 @@ __global__ __launch_bounds__(Q_THREADS) void k_generate(RtTileMap tm, RtParams P
         const uint32_t g = q < total ? frame * tm.nSlots + slot : RT_INVALID;
         uint32_t px = 0, py = 0;
         const bool active = q < total && tm.slot_to_pixel(slot, &px, &py);
-        if (q < total && (CLEAR_RT || !active)) img[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        // padding slots of the image read 0.  A live CSMain path gets its radiance sum and its energy from the first shading
+        // pass, which knows both start values (0 and 1) without reading them; a live ShadowMap pixel is written by its pass
+        if (q < total && !active) img[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         stage[it * Q_THREADS + threadIdx.x] = active ? g : RT_INVALID;
     }
     // the ray of an active path is made once its place in the queue is known, and written there
@@ -349,7 +351,6 @@ __global__ __launch_bounds__(Q_THREADS) void k_generate(RtTileMap tm, RtParams P
         if (P.flags & DOF_FLAG) d_dof_camera_ray(P, r, uvx, uvy, o, d);
         else d_camera_ray(P, uvx, uvy, o, d);
         ray_record_store(ray, at, o, d, g);
-        if (CLEAR_RT) pe[g] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
         rng[g] = make_uint2(r.state, __float_as_uint(r.seed));
     });
 }
@@ -444,8 +445,9 @@ __global__ __launch_bounds__(Q_THREADS) void k_shade(RtSceneView sv, RtBruteView
     if (i != RT_INVALID) {
         const float4 r0 = rayIn[2 * (size_t)i], r1 = rayIn[2 * (size_t)i + 1];
         const uint32_t slot = __float_as_uint(r1.z);
-        const float4 e4 = pe[slot];
-        float4 c4 = rt[slot];
+        // the first segment starts with energy 1 and no radiance (RayTracing.compute:67-68): nothing to read
+        const float4 e4 = bounce == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : pe[slot];
+        const float4 c4 = bounce == 0 ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : rt[slot];
         const RtHitRec h = hitRec[i];
         DRay ray;
         ray.origin = rt_mk3(r0.x, r0.y, r0.z);
