@@ -515,8 +515,8 @@ def main():
             "per_frame_dropin": None if dropin_ms is None else {
                 "ms_per_frame_1spp": round(dropin_ms, 4), "frames": dropin_frames,
                 "ms_per_frame_with_a_full_frame_readback": dropin_readback_ms,
-                "sequence": "rt_set_params(seed) + rt_dispatch + rt_dispatch_shadowmap + rt_accumulate per frame (RayTracing.cs:118-164), "
-                            "one frame in flight"},
+                "sequence": "rt_set_params(seed) + rt_dispatch + rt_dispatch_shadowmap + rt_accumulate per frame (RayTracing.cs:118-164); "
+                            "the library keeps two such frames in flight (RT_OPT_PIPELINE_FRAMES)"},
             "paths_per_step": args.width * args.height * args.spp,
             "bvh_build_ms": round(build_ms, 3),
             "bvh_build_first_ms": round(build_first_ms, 3),

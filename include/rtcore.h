@@ -480,6 +480,15 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *                          finds), so the hits are the same bit for bit; 0 = one level per step.  The kernels that count
  *                          work (rt_enable_counters) walk the same way as the others: internalVisits counts the places of
  *                          the records fetched that hold a child (two per node visited with one level per step).
+ *   RT_OPT_PIPELINE_FRAMES 1 (default): the per-frame call sequence -- rt_set_params (new seed), rt_dispatch, rt_dispatch_shadowmap,
+ *                          rt_accumulate per frame, as RayTracing.CustomRender makes it (RayTracing.cs:118-164) -- keeps TWO
+ *                          frames in flight: consecutive frames go down two lanes (stream, frame of path state, counter
+ *                          block, masked streams, spill areas of their own), so the launches of a frame fill the idle time
+ *                          of the frame before, most of whose launches are as long as their longest ray.  The folds into
+ *                          the running mean stay in frame order (each waits for the one before), so the images keep their
+ *                          bits; RT_IMAGE_RT / RT_IMAGE_SHADOWMAP show the frame of the last rt_dispatch.  Any call other
+ *                          than those four (and rt_set_dirty) first lets both lanes run out.  Off while counters or kernel
+ *                          timing are enabled, with RT_OPT_TWO_STREAMS and with the brute-force flag.
  *   RT_OPT_OVERLAP_AFTER   0..6, default 0: the bounce whose extend launch the overlap starts after (0: as soon as the
  *                          primary hits are known)
  *   RT_OPT_OVERLAP_CUS     compute units the bounce launches keep meanwhile, default 64 (multiples of 32 measured best);
@@ -500,6 +509,7 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
 #define RT_OPT_PRUNE_BY_DISTANCE 12
 #define RT_OPT_SHARE_LONG_WALKS 13
 #define RT_OPT_WIDE_NODES 14
+#define RT_OPT_PIPELINE_FRAMES 15
 int rt_set_option(RtContext *ctx, int option, int value);
 
 /* ------------------------------------------------------------------- stats */

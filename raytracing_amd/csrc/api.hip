@@ -70,10 +70,20 @@ static int use_device(RtContext *ctx)
     return RT_OK;
 }
 
-#define RT_ENTER(ctx)                                   \
+// The calls a host makes once per frame (rt_set_params, rt_dispatch, rt_dispatch_shadowmap, rt_accumulate, rt_set_dirty)
+// leave the two frame lanes running side by side; every other call first makes lane 0's stream wait for lane 1's, so
+// that what it then does on, or waits for with, ctx->stream covers all work in flight.
+#define RT_ENTER_FRAME(ctx)                             \
     if (!(ctx)) return RT_E_INVALID;                    \
     {                                                   \
         int rc__ = use_device(ctx);                     \
+        if (rc__) return rc__;                          \
+    }
+
+#define RT_ENTER(ctx)                                   \
+    RT_ENTER_FRAME(ctx);                                \
+    {                                                   \
+        int rc__ = rt_join_lanes(ctx);                  \
         if (rc__) return rc__;                          \
     }
 
@@ -133,6 +143,11 @@ int rt_create(int device_id, RtContext **out_ctx)
         hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->evFork1, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->evJoin1, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->evAccumulated[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->evAccumulated[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->evLane1Idle, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void **)&ctx->dStats, 64 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&ctx->dNonCasters, RT_NONCASTER_LIST * 64) != hipSuccess ||
         hipMalloc((void **)&ctx->dErrorFlag, 4) != hipSuccess || hipMalloc((void **)&ctx->dQCount, RT_COUNTER_BLOCK_WORDS * 4) != hipSuccess ||
@@ -159,10 +174,12 @@ int rt_destroy(RtContext *ctx)
     // stream shared with other contexts; the main stream is made to wait for it, then drained
     if (ctx->stream) {
         (void)rt_eager_cancel(ctx);
+        (void)rt_join_lanes(ctx);
         (void)hipStreamSynchronize(ctx->stream);
     }
-    if (ctx->streamShadow) (void)hipStreamSynchronize(ctx->streamShadow);
-    if (ctx->streamChain) (void)hipStreamSynchronize(ctx->streamChain);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    for (hipStream_t st : {ctx->streamShadow, ctx->streamChain, ctx->streamShadow1, ctx->streamChain1})
+        if (st) (void)hipStreamSynchronize(st);
     rt_timer_resolve(ctx);
     for (hipEvent_t e : ctx->eventPool) (void)hipEventDestroy(e);
     rt_free_build(ctx);
@@ -182,8 +199,8 @@ int rt_destroy(RtContext *ctx)
     if (ctx->dReadbackFull) (void)hipFree(ctx->dReadbackFull);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2), (void)hipStreamDestroy(ctx->stream2);
     rt_release_overlap_streams(ctx);
-    if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
-    if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
+    for (hipEvent_t e : {ctx->evFork, ctx->evJoin, ctx->evFork1, ctx->evJoin1, ctx->evAccumulated[0], ctx->evAccumulated[1], ctx->evLane1Idle})
+        if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RT_OK;
@@ -334,7 +351,11 @@ int rt_readback_sort_stages(RtContext *ctx, uint32_t *morton_unsorted, uint32_t 
 
 int rt_set_params(RtContext *ctx, const RtParams *p)
 {
-    RT_ENTER_CHANGING(ctx);
+    RT_ENTER_FRAME(ctx);         // (a new seed, a moved camera: the frames in flight keep the uniforms they were launched with)
+    {
+        const int eagerRc = rt_eager_cancel(ctx);
+        if (eagerRc) return eagerRc;
+    }
     if (!p) return rt_fail(ctx, RT_E_INVALID, "null params");
     if (p->width <= 0 || p->height <= 0 || p->width > 32768 || p->height > 32768)
         return rt_fail(ctx, RT_E_INVALID, "bad image size %d x %d", p->width, p->height);
@@ -363,6 +384,8 @@ int rt_set_params(RtContext *ctx, const RtParams *p)
     ctx->tile = tm;
     ctx->paramsSet = true;
     if (geometryChanged) {
+        const int joinRc = rt_join_lanes(ctx);
+        if (joinRc) return joinRc;
         RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return rt_alloc_render(ctx);   // new render targets: InitRT resets samplePrePixel (RayTracing.cs:172-187)
     }
@@ -382,7 +405,7 @@ static int ready_to_render(RtContext *ctx, bool csMain, bool shadowMap)
 
 int rt_dispatch(RtContext *ctx)
 {
-    RT_ENTER(ctx);
+    RT_ENTER_FRAME(ctx);
     int rc = ready_to_render(ctx, true, false);
     if (rc) return rc;   // CustomRender returns silently when not initialised (RayTracing.cs:120-121); here it is an error code
     return rt_dispatch_impl(ctx);
@@ -390,7 +413,7 @@ int rt_dispatch(RtContext *ctx)
 
 int rt_dispatch_shadowmap(RtContext *ctx)
 {
-    RT_ENTER(ctx);
+    RT_ENTER_FRAME(ctx);
     int rc = ready_to_render(ctx, false, true);
     if (rc) return rc;
     return rt_shadowmap_impl(ctx);
@@ -398,7 +421,7 @@ int rt_dispatch_shadowmap(RtContext *ctx)
 
 int rt_accumulate(RtContext *ctx, uint32_t sample_per_pixel, int use_shadow_map)
 {
-    RT_ENTER(ctx);
+    RT_ENTER_FRAME(ctx);
     if (!ctx->paramsSet) return rt_fail(ctx, RT_E_STATE, "rt_set_params has not been called");
     return rt_accumulate_impl(ctx, sample_per_pixel, use_shadow_map);
 }
@@ -493,7 +516,7 @@ int rt_readback_merge(RtContext *ctx, int which, float *frame_rgba)
  * the caller's memory while the next frames are rendered. */
 int rt_readback_async(RtContext *ctx, int which, float *pinned_dst_rgba)
 {
-    RT_ENTER(ctx);
+    RT_ENTER_FRAME(ctx);          // a per-frame call: the two frame lanes keep running
     if (!pinned_dst_rgba) return rt_fail(ctx, RT_E_INVALID, "null destination");
     if (!ctx->paramsSet) return rt_fail(ctx, RT_E_STATE, "rt_set_params has not been called");
     if (which != RT_IMAGE_RT && which != RT_IMAGE_CONVERGED && which != RT_IMAGE_SHADOWMAP)
@@ -506,29 +529,21 @@ int rt_readback_async(RtContext *ctx, int which, float *pinned_dst_rgba)
         RT_HIP(ctx, hipEventCreateWithFlags(&ctx->evExpanded, hipEventDisableTiming));
         RT_HIP(ctx, hipEventCreateWithFlags(&ctx->evCopied, hipEventDisableTiming));
     }
-    if (ctx->copyPending) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evCopied, 0));   // the staging frame is still being read
     if (ctx->readbackPixels != px) {
         if (ctx->copyPending) RT_HIP(ctx, hipEventSynchronize(ctx->evCopied));
+        ctx->copyPending = false;
         if (ctx->dReadbackFull) (void)hipFree(ctx->dReadbackFull);
         ctx->dReadbackFull = nullptr;
         ctx->readbackPixels = 0;
         RT_HIP(ctx, hipMalloc((void **)&ctx->dReadbackFull, (px ? px : 1) * sizeof(float4)));
         ctx->readbackPixels = px;
     }
-    if (ctx->tile.count > 1) RT_HIP(ctx, hipMemsetAsync(ctx->dReadbackFull, 0, px * sizeof(float4), ctx->stream));   // other ranks' pixels read 0
-    int rc = rt_expand_local_impl(ctx, src, ctx->dReadbackFull);
-    if (rc) return rc;
-    RT_HIP(ctx, hipEventRecord(ctx->evExpanded, ctx->stream));
-    RT_HIP(ctx, hipStreamWaitEvent(ctx->streamCopy, ctx->evExpanded, 0));
-    RT_HIP(ctx, hipMemcpyAsync(pinned_dst_rgba, ctx->dReadbackFull, px * sizeof(float4), hipMemcpyDeviceToHost, ctx->streamCopy));
-    RT_HIP(ctx, hipEventRecord(ctx->evCopied, ctx->streamCopy));
-    ctx->copyPending = true;
-    return RT_OK;
+    return rt_readback_async_impl(ctx, src, pinned_dst_rgba);
 }
 
 int rt_readback_wait(RtContext *ctx)
 {
-    RT_ENTER(ctx);
+    RT_ENTER_FRAME(ctx);
     if (!ctx->copyPending) return RT_OK;
     RT_HIP(ctx, hipEventSynchronize(ctx->evCopied));
     ctx->copyPending = false;
@@ -724,6 +739,7 @@ int rt_set_option(RtContext *ctx, int option, int value)
         return RT_OK;
     case RT_OPT_SHARE_LONG_WALKS: ctx->optShareLongWalks = value != 0; return RT_OK;
     case RT_OPT_WIDE_NODES: ctx->optWideNodes = value != 0; return RT_OK;
+    case RT_OPT_PIPELINE_FRAMES: ctx->optPipelineFrames = value != 0; return RT_OK;
     case RT_OPT_PACKET_SHADOW: ctx->optPacketShadow = value != 0; return RT_OK;
     case RT_OPT_PACKET_PRIMARY: ctx->optPacketPrimary = value != 0; return RT_OK;
     case RT_OPT_PACKET_TRACE: ctx->optPacketTrace = value != 0; return RT_OK;

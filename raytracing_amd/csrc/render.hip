@@ -11,6 +11,9 @@
 // is a sequence of launches over compacted queues of live paths:
 //   generate -> { extend (traverse) -> shade (+ wave64 ballot compaction) } x 8
 // Path state lives in SoA arrays indexed by tile-local slot; queues hold slots.
+#include <new>
+#include <utility>
+
 #include "rt_internal.h"
 #include "rt_shade.h"
 
@@ -806,7 +809,7 @@ int rt_alloc_render(RtContext *ctx)
     RT_HIP(ctx, hipMemsetAsync(ctx->dConv, 0, m * sizeof(float4), ctx->stream));
     ctx->allocSlots = n;
     ctx->sampleCount = 0;
-    return alloc_batch(ctx, 1);
+    return alloc_batch(ctx, 2);     // a frame of path state for each lane of the per-frame call sequence
 }
 
 // Frames rt_render_frames keeps in flight for a tile share of nSlots path slots: `option` = RT_OPT_BATCH_FRAMES
@@ -972,7 +975,7 @@ static uint32_t walker_blocks_per_cu()
 // when the last of those contexts is destroyed; the split is the one the first of them asked for.
 struct RtMaskedStreams {
     uint32_t few = 0, users = 0;
-    hipStream_t shadow = nullptr, chain = nullptr;
+    hipStream_t shadow[2] = {nullptr, nullptr}, chain[2] = {nullptr, nullptr};   // a pair per frame lane, same masks
 };
 static std::mutex g_maskedMutex;
 static std::map<int, RtMaskedStreams> g_masked;
@@ -990,18 +993,29 @@ static bool overlap_streams_ready(RtContext *ctx)
         const uint32_t words = (n + 31u) / 32u;
         std::vector<uint32_t> most(words, 0u), rest(words, 0u);
         for (uint32_t cu = 0; cu < n; ++cu) (cu < n - few ? most : rest)[cu >> 5] |= 1u << (cu & 31u);
-        if (hipExtStreamCreateWithCUMask(&m.shadow, words, most.data()) != hipSuccess ||
-            hipExtStreamCreateWithCUMask(&m.chain, words, rest.data()) != hipSuccess) {
+        bool ok = true;
+        for (int lane = 0; lane < 2 && ok; ++lane)
+            ok = hipExtStreamCreateWithCUMask(&m.shadow[lane], words, most.data()) == hipSuccess &&
+                 hipExtStreamCreateWithCUMask(&m.chain[lane], words, rest.data()) == hipSuccess;
+        if (!ok) {
             (void)hipGetLastError();             // no masked queues here: the plain order is used
-            if (m.shadow) (void)hipStreamDestroy(m.shadow);
-            m.shadow = m.chain = nullptr;
+            for (int lane = 0; lane < 2; ++lane) {
+                if (m.shadow[lane]) (void)hipStreamDestroy(m.shadow[lane]);
+                if (m.chain[lane]) (void)hipStreamDestroy(m.chain[lane]);
+                m.shadow[lane] = m.chain[lane] = nullptr;
+            }
             return false;
         }
         m.few = few;
     }
     m.users += 1;
-    ctx->streamShadow = m.shadow;
-    ctx->streamChain = m.chain;
+    // (a context asks from inside a frame lane's scope, where its lane-0 fields are swapped with its lane-1 fields: both sets
+    //  are filled either way round)
+    const bool swapped = ctx->spillArea == 2;
+    (swapped ? ctx->streamShadow1 : ctx->streamShadow) = m.shadow[0];
+    (swapped ? ctx->streamChain1 : ctx->streamChain) = m.chain[0];
+    (swapped ? ctx->streamShadow : ctx->streamShadow1) = m.shadow[1];
+    (swapped ? ctx->streamChain : ctx->streamChain1) = m.chain[1];
     ctx->overlapCUs = m.few;
     return true;
 }
@@ -1011,14 +1025,18 @@ void rt_release_overlap_streams(RtContext *ctx)
     if (!ctx->overlapCUs) return;
     std::lock_guard<std::mutex> lock(g_maskedMutex);
     RtMaskedStreams &m = g_masked[ctx->device];
-    (void)hipStreamSynchronize(m.shadow);
-    (void)hipStreamSynchronize(m.chain);
+    for (int lane = 0; lane < 2; ++lane) {
+        (void)hipStreamSynchronize(m.shadow[lane]);
+        (void)hipStreamSynchronize(m.chain[lane]);
+    }
     if (--m.users == 0) {
-        (void)hipStreamDestroy(m.shadow);
-        (void)hipStreamDestroy(m.chain);
+        for (int lane = 0; lane < 2; ++lane) {
+            (void)hipStreamDestroy(m.shadow[lane]);
+            (void)hipStreamDestroy(m.chain[lane]);
+        }
         m = RtMaskedStreams();
     }
-    ctx->streamShadow = ctx->streamChain = nullptr;
+    ctx->streamShadow = ctx->streamChain = ctx->streamShadow1 = ctx->streamChain1 = nullptr;
     ctx->overlapCUs = 0;
 }
 
@@ -1028,7 +1046,7 @@ static int overlap_fork(RtContext *ctx, const RtSceneView &sceneView, uint32_t t
 {
     RtSceneView sv = sceneView;
     sv.stats = ctx->dStats + 32;
-    sv.stackSpill = ctx->dStackSpill + (size_t)ctx->numCU * RT_SPILL_WORDS_PER_CU;     // the second spill area
+    sv.stackSpill = ctx->dStackSpill + (size_t)(ctx->spillArea + 1u) * ctx->numCU * RT_SPILL_WORDS_PER_CU;   // the area next to the one the lane's own stream uses
     ShadowSrcOverlapped sh;
     static_cast<ShadowSrc &>(sh) = shadow_source(ctx);
     RT_HIP(ctx, hipEventRecord(ctx->evFork, ctx->stream));
@@ -1175,13 +1193,110 @@ static int overlap_choice(RtContext *ctx, bool shared)
     return -1;
 }
 
+// While alive, every per-path buffer of the context points `firstFrame` frames further on, work goes to
+// `stream`, the queue counters to `counters` and deep stack levels to spill area `area`: the launch helpers then work
+// on a sub-range of the frames in flight without knowing it.  frameLane: the scope is the second lane of the per-frame
+// call sequence, which also has events and masked streams of its own (swapped with lane 0's while the scope lives).
+struct RtLaneScope {
+    RtContext *ctx;
+    hipStream_t stream;
+    float4 *rt, *sm, *pe, *smRec, *smRecQ, *ray0, *ray1;
+    uint2 *rng;
+    RtHitRec *hit;
+    uint32_t *smq, *cnt;
+    uint8_t *smFlags;
+    float *seeds;
+    bool frameLane;
+    RtLaneScope(RtContext *c, hipStream_t s, uint32_t firstFrame, uint32_t *counters, uint32_t area = 1, bool secondFrameLane = false)
+        : ctx(c), stream(c->stream), rt(c->dRt), sm(c->dShadowMap), pe(c->dPe), smRec(c->dSmRec), smRecQ(c->dSmRecQ), ray0(c->dRay[0]), ray1(c->dRay[1]), rng(c->dRng),
+          hit(c->dHit), smq(c->dSmQueue), cnt(c->dQCount), smFlags(c->dSmFlags), seeds(c->dSeeds), frameLane(secondFrameLane)
+    {
+        const size_t off = (size_t)firstFrame * c->tile.nSlots;
+        c->stream = s;
+        c->dRt += off; c->dShadowMap += off; c->dPe += off; c->dRng += off; c->dHit += off;
+        c->dRay[0] += 2 * off; c->dRay[1] += 2 * off; c->dSmQueue += off; c->dSmRec += 2 * off; c->dSmRecQ += 2 * off; c->dSmFlags += 16 * off;
+        c->dSeeds += firstFrame;
+        c->dQCount = counters;
+        c->spillArea = area;     // (two streams of one batch: area 1 -- the overlapped shadow launch, its other user, is off then)
+        if (frameLane) swap_lane_fields();
+    }
+    void swap_lane_fields()
+    {
+        RtContext *c = ctx;
+        std::swap(c->evFork, c->evFork1);
+        std::swap(c->evJoin, c->evJoin1);
+        std::swap(c->streamShadow, c->streamShadow1);
+        std::swap(c->streamChain, c->streamChain1);
+    }
+    ~RtLaneScope()
+    {
+        RtContext *c = ctx;
+        if (frameLane) swap_lane_fields();
+        c->stream = stream;
+        c->dRt = rt; c->dShadowMap = sm; c->dPe = pe; c->dSmRec = smRec; c->dSmRecQ = smRecQ; c->dRng = rng; c->dHit = hit;
+        c->dRay[0] = ray0; c->dRay[1] = ray1; c->dSmQueue = smq; c->dQCount = cnt; c->dSmFlags = smFlags; c->dSeeds = seeds;
+        c->spillArea = 0;
+    }
+};
+
+// ---- two frames of the per-frame call sequence in flight (RT_OPT_PIPELINE_FRAMES)
+// A host that keeps the reference's loop calls rt_set_params (new seed), rt_dispatch, rt_dispatch_shadowmap, rt_accumulate
+// once per frame (RayTracing.cs:118-164).  One frame by itself is a chain of two dozen launches most of which are as
+// long as their longest ray and leave the chip nearly idle; so consecutive frames go down two lanes -- two streams, two
+// frames of path state, two counter blocks, their own masked streams and spill areas -- and the launches of frame k + 1
+// fill the idle time of frame k's.  What orders them is data: a lane's stream keeps its own frames in order, and the
+// fold of a frame into the running mean waits for the fold of the frame before it (evAccumulated), so the mean is
+// built in frame order with the same operations -- same bits as one frame after the other.
+static bool lanes_active(RtContext *ctx)
+{
+    return ctx->optPipelineFrames && !ctx->countersOn && !ctx->timingOn && !ctx->optTwoStreams && ctx->stream2 && ctx->batchCap >= 2 &&
+           !(ctx->params.flags & RT_FLAG_BRUTE_FORCE);
+}
+
+struct RtFrameLane {
+    char room[sizeof(RtLaneScope)];
+    RtLaneScope *scope = nullptr;
+    RtFrameLane(RtContext *ctx, uint32_t lane)
+    {
+        if (lane == 1u) {
+            if (!ctx->lane1Busy) {
+                // the lane starts up (again): after everything lane 0's stream holds so far -- a batch of rt_render_frames
+                // may still be at work in the frame of path state that is lane 1's
+                (void)hipEventRecord(ctx->evLane1Idle, ctx->stream);
+                (void)hipStreamWaitEvent(ctx->stream2, ctx->evLane1Idle, 0);
+            }
+            scope = new (room) RtLaneScope(ctx, ctx->stream2, 1, ctx->dQCount + CNT_WORDS, 2, true);
+            ctx->lane1Busy = true;
+        }
+    }
+    RtFrameLane(const RtFrameLane &) = delete;
+    RtFrameLane &operator=(const RtFrameLane &) = delete;
+    ~RtFrameLane()
+    {
+        if (scope) scope->~RtLaneScope();
+    }
+};
+
+int rt_join_lanes(RtContext *ctx)
+{
+    ctx->nextLane = 0;
+    if (!ctx->lane1Busy) return RT_OK;
+    RT_HIP(ctx, hipEventRecord(ctx->evLane1Idle, ctx->stream2));
+    RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evLane1Idle, 0));
+    ctx->lane1Busy = false;
+    return RT_OK;
+}
+
 // A ShadowMap pass that rt_dispatch started and nobody asked for yet is dropped: the main stream waits for
 // its launch (the buffers it works on are about to be reused) and the next rt_dispatch_shadowmap starts over.
 int rt_eager_cancel(RtContext *ctx)
 {
     const int state = ctx->eagerShadow;
     ctx->eagerShadow = RT_EAGER_NONE;
-    if (state == RT_EAGER_FORKED) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evJoin, 0));
+    if (state == RT_EAGER_FORKED) {
+        RtFrameLane lane(ctx, ctx->frameLane);
+        RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evJoin, 0));
+    }
     return RT_OK;
 }
 
@@ -1193,23 +1308,36 @@ int rt_dispatch_impl(RtContext *ctx)
 {
     int rc = rt_eager_cancel(ctx);
     if (rc) return rc;
-    if ((rc = upload_seeds(ctx, &ctx->params.seed, 1))) return rc;
-    const bool eager = ctx->optEagerShadowMap && (ctx->params.flags & RT_FLAG_MATTE_MASK) && shadow_shares_primary(ctx->params) &&
-                       ctx->built && !ctx->countersOn && ctx->tile.nSlots != 0;
-    if (!eager) return dispatch_frames(ctx, 1, false);
-    const int overlapAfter = overlap_choice(ctx, true);
-    rc = dispatch_frames(ctx, 1, true, overlapAfter);
-    const int rc2 = overlap_chain_done(ctx);
-    if (rc || rc2) return rc ? rc : rc2;
-    ctx->eagerShadow = overlapAfter >= 0 ? RT_EAGER_FORKED : RT_EAGER_SETUP;
-    return RT_OK;
+    const uint32_t laneOfFrame = lanes_active(ctx) ? ctx->nextLane : 0u;
+    if (!lanes_active(ctx) && (rc = rt_join_lanes(ctx))) return rc;
+    ctx->nextLane = lanes_active(ctx) ? laneOfFrame ^ 1u : 0u;
+    ctx->frameLane = laneOfFrame;
+    {
+        RtFrameLane lane(ctx, laneOfFrame);
+        if ((rc = upload_seeds(ctx, &ctx->params.seed, 1))) return rc;
+        const bool eager = ctx->optEagerShadowMap && (ctx->params.flags & RT_FLAG_MATTE_MASK) && shadow_shares_primary(ctx->params) &&
+                           ctx->built && !ctx->countersOn && ctx->tile.nSlots != 0;
+        if (!eager) {
+            rc = dispatch_frames(ctx, 1, false);
+        } else {
+            const int overlapAfter = overlap_choice(ctx, true);
+            rc = dispatch_frames(ctx, 1, true, overlapAfter);
+            const int rc2 = overlap_chain_done(ctx);
+            if (!rc) rc = rc2;
+            if (!rc) ctx->eagerShadow = overlapAfter >= 0 ? RT_EAGER_FORKED : RT_EAGER_SETUP;
+        }
+    }
+    ctx->lastFrame = laneOfFrame;
+    return rc;
 }
 
 int rt_shadowmap_impl(RtContext *ctx)
 {
     const int state = ctx->eagerShadow;
     ctx->eagerShadow = RT_EAGER_NONE;
-    ctx->lastFrame = 0;
+    const uint32_t laneOfFrame = ctx->frameLane;
+    ctx->lastFrame = laneOfFrame;
+    RtFrameLane lane(ctx, laneOfFrame);
     if (state == RT_EAGER_FORKED) return overlap_finish(ctx, rt_scene_view(ctx), ctx->tile.nSlots);
     if (state == RT_EAGER_SETUP) {
         launch_shadow_rays(ctx, rt_scene_view(ctx), ctx->tile.nSlots);
@@ -1235,42 +1363,17 @@ static int accumulate_frames(RtContext *ctx, uint32_t frames, uint32_t samplePer
 
 int rt_accumulate_impl(RtContext *ctx, uint32_t samplePerPixel, int useShadowMap)
 {
-    return accumulate_frames(ctx, 1, samplePerPixel, useShadowMap, ctx->lastFrame);
+    const uint32_t laneOfFrame = ctx->frameLane;
+    const size_t frame = laneOfFrame == 1u ? 0u : ctx->lastFrame;     // (lane 1's scope has moved the frame pointers on already)
+    RtFrameLane lane(ctx, laneOfFrame);
+    // the running mean is built in frame order: this fold after the fold of the frame before, which the other lane made
+    if (ctx->accumulatedPending[laneOfFrame ^ 1u]) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evAccumulated[laneOfFrame ^ 1u], 0));
+    const int rc = accumulate_frames(ctx, 1, samplePerPixel, useShadowMap, frame);
+    if (rc) return rc;
+    RT_HIP(ctx, hipEventRecord(ctx->evAccumulated[laneOfFrame], ctx->stream));
+    ctx->accumulatedPending[laneOfFrame] = true;
+    return RT_OK;
 }
-
-// While alive, every per-path buffer of the context points `firstFrame` frames further on, work goes to
-// `stream` and the queue counters to `counters`: the launch helpers above then work on a sub-range of the
-// frames in flight without knowing it.
-struct RtLaneScope {
-    RtContext *ctx;
-    hipStream_t stream;
-    float4 *rt, *sm, *pe, *smRec, *smRecQ, *ray0, *ray1;
-    uint2 *rng;
-    RtHitRec *hit;
-    uint32_t *smq, *cnt;
-    uint8_t *smFlags;
-    float *seeds;
-    RtLaneScope(RtContext *c, hipStream_t s, uint32_t firstFrame, uint32_t *counters)
-        : ctx(c), stream(c->stream), rt(c->dRt), sm(c->dShadowMap), pe(c->dPe), smRec(c->dSmRec), smRecQ(c->dSmRecQ), ray0(c->dRay[0]), ray1(c->dRay[1]), rng(c->dRng),
-          hit(c->dHit), smq(c->dSmQueue), cnt(c->dQCount), smFlags(c->dSmFlags), seeds(c->dSeeds)
-    {
-        const size_t off = (size_t)firstFrame * c->tile.nSlots;
-        c->stream = s;
-        c->dRt += off; c->dShadowMap += off; c->dPe += off; c->dRng += off; c->dHit += off;
-        c->dRay[0] += 2 * off; c->dRay[1] += 2 * off; c->dSmQueue += off; c->dSmRec += 2 * off; c->dSmRecQ += 2 * off; c->dSmFlags += 16 * off;
-        c->dSeeds += firstFrame;
-        c->dQCount = counters;
-        c->spillArea = 1;        // the overlapped shadow launch, the other user of area 1, is off with two streams
-    }
-    ~RtLaneScope()
-    {
-        RtContext *c = ctx;
-        c->stream = stream;
-        c->dRt = rt; c->dShadowMap = sm; c->dPe = pe; c->dSmRec = smRec; c->dSmRecQ = smRecQ; c->dRng = rng; c->dHit = hit;
-        c->dRay[0] = ray0; c->dRay[1] = ray1; c->dSmQueue = smq; c->dQCount = cnt; c->dSmFlags = smFlags; c->dSeeds = seeds;
-        c->spillArea = 0;
-    }
-};
 
 static int render_lane(RtContext *ctx, uint32_t frames, bool matte, bool shared)
 {
@@ -1325,6 +1428,28 @@ int rt_render_frames_impl(RtContext *ctx, const float *seeds, uint32_t nFrames)
         ctx->sampleCount += f;
         ctx->params.seed = seeds[base + f - 1];
     }
+    return RT_OK;
+}
+
+// rt_readback_async: on the stream of the frame that was dispatched last (its lane), behind that frame's fold, the image
+// is expanded into the staging frame; the copy stream takes it from there.  The next frame's fold -- the other lane's --
+// waits for this lane's evAccumulated, which is moved behind the expansion: the running mean is not folded further
+// before it has been staged.
+int rt_readback_async_impl(RtContext *ctx, const float4 *src, float *pinnedDst)
+{
+    const uint32_t laneOfFrame = ctx->frameLane;
+    const size_t px = (size_t)ctx->params.width * ctx->params.height;
+    RtFrameLane lane(ctx, laneOfFrame);
+    if (ctx->copyPending) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evCopied, 0));      // the staging frame is still being read
+    if (ctx->tile.count > 1) RT_HIP(ctx, hipMemsetAsync(ctx->dReadbackFull, 0, px * sizeof(float4), ctx->stream));   // other ranks' pixels read 0
+    const int rc = rt_expand_local_impl(ctx, src, ctx->dReadbackFull);
+    if (rc) return rc;
+    RT_HIP(ctx, hipEventRecord(ctx->evExpanded, ctx->stream));
+    if (ctx->accumulatedPending[laneOfFrame]) RT_HIP(ctx, hipEventRecord(ctx->evAccumulated[laneOfFrame], ctx->stream));
+    RT_HIP(ctx, hipStreamWaitEvent(ctx->streamCopy, ctx->evExpanded, 0));
+    RT_HIP(ctx, hipMemcpyAsync(pinnedDst, ctx->dReadbackFull, px * sizeof(float4), hipMemcpyDeviceToHost, ctx->streamCopy));
+    RT_HIP(ctx, hipEventRecord(ctx->evCopied, ctx->streamCopy));
+    ctx->copyPending = true;
     return RT_OK;
 }
 

@@ -194,16 +194,28 @@ struct RtPendingEvent {
 #define RT_COUNTER_BLOCK_WORDS 1536 // queue counts and ray cursors (dQCount), a 128-byte line each, one set per stream
 #define RT_SPILL_WORDS_PER_CU (2048 * RT_STACK_DEPTH)   // room for every stack level of 2048 lanes per CU
 #define RT_NONCASTER_LIST 8                             // non-casting triangles a shadow ray is tested against one by one
-#define RT_SPILL_AREAS 2                                // walker launches that may be on the chip together
+#define RT_SPILL_AREAS 4                                // walker launches that may be on the chip together: per frame lane (two), the
+                                                        // launches of its own stream and the shadow-ray launch that overlaps them
 
 struct RtPostState;   // post.hip
 
 struct RtContext {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;        // second half of the frames in flight (rt_render_frames)
+    hipStream_t stream2 = nullptr;        // second half of the frames in flight (rt_render_frames); every other frame of the per-frame calls
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     hipStream_t streamShadow = nullptr, streamChain = nullptr;   // queues masked to most / the remaining few compute units (process-wide)
+    // Two frames of the per-frame call sequence in flight (RT_OPT_PIPELINE_FRAMES): frames alternate between two lanes, each
+    // with its own stream, masked streams, events, frame of path state, counter block and spill areas.  The fields above are
+    // lane 0's; while lane 1's calls are made they are swapped for these (RtLaneScope).
+    hipEvent_t evFork1 = nullptr, evJoin1 = nullptr;
+    hipStream_t streamShadow1 = nullptr, streamChain1 = nullptr;
+    hipEvent_t evAccumulated[2] = {nullptr, nullptr};   // after a lane's rt_accumulate: the next frame's fold waits for it
+    hipEvent_t evLane1Idle = nullptr;
+    bool accumulatedPending[2] = {false, false};
+    bool lane1Busy = false;               // lane 1's stream may hold work that lane 0's stream has not waited for
+    bool optPipelineFrames = true;
+    uint32_t frameLane = 0, nextLane = 0; // the lane of the frame rt_dispatch last started, and of the next one
     hipStream_t streamMain = nullptr;     // the caller's stream while ctx->stream is the chain stream
     uint32_t overlapCUs = 0;              // the split the two masked streams were made for (0: none held)
     bool overlapTried = false;
@@ -377,6 +389,7 @@ struct RtArena {
 
 enum { RT_EAGER_NONE = 0, RT_EAGER_SETUP = 1, RT_EAGER_FORKED = 2 };   // nothing / pass prepared / its rays already being walked
 int rt_eager_cancel(RtContext *ctx);
+int rt_join_lanes(RtContext *ctx);    // lane 0's stream waits for what lane 1's holds: after it, draining ctx->stream drains everything
 uint32_t rt_batch_frames_rule(uint32_t nSlots, uint32_t option, uint32_t wanted);
 void rt_free_render(RtContext *ctx);
 int rt_dispatch_impl(RtContext *ctx);
@@ -386,6 +399,7 @@ int rt_render_frames_impl(RtContext *ctx, const float *seeds, uint32_t nFrames);
 int rt_trace_device_impl(RtContext *ctx, const float4 *o, const float4 *d, uint32_t n, RtHitRec *hits);
 int rt_static_scratch_init(RtContext *ctx);   // once per device, from rt_create
 int rt_trace_device_static_impl(RtContext *ctx, const float4 *o, const float4 *d, uint32_t n, RtHitRec *hits);
+int rt_readback_async_impl(RtContext *ctx, const float4 *src, float *pinnedDst);
 int rt_expand_local_impl(RtContext *ctx, const float4 *local, float4 *full);
 int rt_expand_local_on(RtContext *ctx, hipStream_t stream, const float4 *local, float4 *full);   // the same scatter on another stream (of any device that sees both buffers)
 int rt_trace_primitives_impl(RtContext *ctx, const float4 *o, const float4 *d, uint32_t n, float *t, uint32_t *prim, float *normal3);

@@ -675,6 +675,78 @@ def test_shadowmap_pass_started_by_dispatch_gives_the_same_bits(core):
         core.set_option(wire.OPT_EAGER_SHADOWMAP, 1)
 
 
+@pytest.mark.parametrize("scene", ["car with ShadowMap pass", "cornell"])
+def test_two_frames_in_flight_through_the_per_frame_calls_keep_the_bits(core, scene):
+    """The per-frame call sequence keeps two frames in flight (RT_OPT_PIPELINE_FRAMES): the images after every frame and
+    at the end are those of one frame after the other, and of the batch call."""
+    if scene == "cornell":
+        sc = scenes.cornell_box(320, 200, sphere_segments=24)
+    else:
+        sc = scenes.car_standin(384, 256, detail=0.15)
+    use_shadow = bool(sc.params.flags & wire.FLAG_MATTE_MASK)
+    seeds = scenes.frame_seeds(7, seed=33)
+    core.upload(sc)
+    core.bvh_build()
+
+    def run(pipeline, peek=False, upto=None):
+        core.set_option(wire.OPT_PIPELINE_FRAMES, pipeline)
+        p = sc.params.copy()
+        core.set_params(p)
+        core.set_dirty()
+        frames = []
+        for k, seed in enumerate(seeds[:upto]):
+            p.seed = float(seed)
+            core.set_params(p)
+            core.dispatch()
+            if use_shadow:
+                core.dispatch_shadowmap()
+            core.accumulate(k, use_shadow)
+            if peek:                                   # a readback between frames lets both lanes run out first
+                frames.append([core.readback(w) for w in (wire.IMAGE_RT, wire.IMAGE_SHADOWMAP, wire.IMAGE_CONVERGED)])
+        return frames if peek else [core.readback(w) for w in (wire.IMAGE_RT, wire.IMAGE_SHADOWMAP, wire.IMAGE_CONVERGED)]
+
+    names = ("rt", "shadow map", "converged")
+    try:
+        want_frames = run(0, peek=True)
+        for upto in (7, 6, 1):                         # the last frame on either lane
+            got = run(1, upto=upto)
+            for name, a, b in zip(names, got, want_frames[upto - 1]):
+                if name != "shadow map" or use_shadow:
+                    H.assert_bits_equal(a, b, f"{name} after {upto} frames, two frames in flight")
+        got_frames = run(1, peek=True)
+        for k, (g, w) in enumerate(zip(got_frames, want_frames)):
+            for name, a, b in zip(names, g, w):
+                if name != "shadow map" or use_shadow:
+                    H.assert_bits_equal(a, b, f"{name} of frame {k}, two frames in flight, read back after every frame")
+        # every frame's running mean read back in the background, without letting the lanes run out
+        import torch
+        pinned = [torch.empty((sc.params.height, sc.params.width, 4), dtype=torch.float32).pin_memory() for _ in seeds]
+        core.set_option(wire.OPT_PIPELINE_FRAMES, 1)
+        p = sc.params.copy()
+        core.set_params(p)
+        core.set_dirty()
+        for k, seed in enumerate(seeds):
+            p.seed = float(seed)
+            core.set_params(p)
+            core.dispatch()
+            if use_shadow:
+                core.dispatch_shadowmap()
+            core.accumulate(k, use_shadow)
+            core.readback_async(wire.IMAGE_CONVERGED, pinned[k].data_ptr())
+        core.readback_wait()
+        for k, w in enumerate(want_frames):
+            H.assert_bits_equal(pinned[k].numpy(), w[2], f"running mean after frame {k}, rt_readback_async, two frames in flight")
+        # the batch call right after the per-frame calls, and the per-frame calls right after a batch
+        run(1, upto=5)
+        core.set_dirty()
+        core.render_frames(seeds)
+        H.assert_bits_equal(core.readback(wire.IMAGE_CONVERGED), want_frames[-1][2], "batch after per-frame calls")
+        got = run(1)
+        H.assert_bits_equal(got[2], want_frames[-1][2], "per-frame calls after a batch")
+    finally:
+        core.set_option(wire.OPT_PIPELINE_FRAMES, 1)
+
+
 def test_spilled_stacks_of_concurrent_launches_do_not_meet(core):
     """A build of the library that keeps two stack levels per lane in LDS instead of sixteen sends nearly every
     ray's stack through the spill areas in device memory.  Launches that run at the same time -- the shadow rays
@@ -713,6 +785,19 @@ def test_spilled_stacks_of_concurrent_launches_do_not_meet(core):
             spill.render_frames(seeds)
             for label, which, ref in zip(("rt", "shadow map", "converged"), (wire.IMAGE_RT, wire.IMAGE_SHADOWMAP, wire.IMAGE_CONVERGED), want):
                 H.assert_bits_equal(spill.readback(which), ref, f"{label}, stacks spilled, {name}")
+        # the per-frame calls keep two frames in flight: four walker launches may be on the chip together
+        for k in (wire.OPT_OVERLAP_SHADOW, wire.OPT_TWO_STREAMS):
+            spill.set_option(k, {wire.OPT_OVERLAP_SHADOW: 1, wire.OPT_TWO_STREAMS: 0}[k])
+        p = sc.params.copy()
+        spill.set_dirty()
+        for k, seed in enumerate(seeds):
+            p.seed = float(seed)
+            spill.set_params(p)
+            spill.dispatch()
+            spill.dispatch_shadowmap()
+            spill.accumulate(k, True)
+        for label, which, ref in zip(("rt", "shadow map", "converged"), (wire.IMAGE_RT, wire.IMAGE_SHADOWMAP, wire.IMAGE_CONVERGED), want):
+            H.assert_bits_equal(spill.readback(which), ref, f"{label}, stacks spilled, per-frame calls with two frames in flight")
         got = spill.trace_rays(o, d)
         for k in ("triangle", "t", "u", "v"):
             H.assert_bits_equal(got[k], want_hits[k], f"{k}: stacks spilled, rt_trace_rays")

@@ -15,6 +15,8 @@ core = native.RtCore(0)
 core.upload(sc); core.bvh_build()
 p = sc.params.copy()
 core.set_params(p)
+for kv in filter(None, os.environ.get("RT_OPTS", "").split(",")):     # rt_set_option pairs, e.g. RT_OPTS=8=128
+    k, v = kv.split("="); core.set_option(int(k), int(v))
 seeds = scenes.frame_seeds(frames + 2, 1)
 core.set_dirty()
 
