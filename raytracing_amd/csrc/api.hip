@@ -744,7 +744,10 @@ int rt_set_option(RtContext *ctx, int option, int value)
     case RT_OPT_PACKET_PRIMARY: ctx->optPacketPrimary = value != 0; return RT_OK;
     case RT_OPT_PACKET_TRACE: ctx->optPacketTrace = value != 0; return RT_OK;
     case RT_OPT_MATERIAL_SORT: ctx->optMaterialSort = value != 0; return RT_OK;
-    case RT_OPT_TWO_STREAMS: ctx->optTwoStreams = value != 0; return RT_OK;
+    case RT_OPT_TWO_STREAMS:
+        if (value < 0 || value > 2) return rt_fail(ctx, RT_E_INVALID, "RT_OPT_TWO_STREAMS must be 0, 1 or 2");
+        ctx->optTwoStreams = value;
+        return RT_OK;
     case RT_OPT_CASTER_BOX: ctx->optCasterBox = value != 0; return RT_OK;
     case RT_OPT_FIRST_HIT_SHADOW: ctx->optFirstHitShadow = value != 0; return RT_OK;
     case RT_OPT_OVERLAP_SHADOW: ctx->optOverlapShadow = value != 0; return RT_OK;

@@ -1186,7 +1186,7 @@ static int upload_seeds(RtContext *ctx, const float *seeds, uint32_t n)
 static int overlap_choice(RtContext *ctx, bool shared)
 {
     // Per-launch counters and event timers describe launches of one stream, one after the other: both keep the plain order.
-    if (shared && ctx->optOverlapShadow && !ctx->optTwoStreams && !ctx->countersOn && !ctx->timingOn && !ctx->optPacketShadow &&
+    if (shared && ctx->optOverlapShadow && ctx->optTwoStreams != 1 && !ctx->countersOn && !ctx->timingOn && !ctx->optPacketShadow &&
         !(ctx->params.flags & RT_FLAG_BRUTE_FORCE) && ctx->tile.nSlots != 0 && ctx->optOverlapAfter + 1 < RT_MAX_BOUNCE &&
         overlap_streams_ready(ctx))
         return (int)ctx->optOverlapAfter;
@@ -1412,17 +1412,21 @@ int rt_render_frames_impl(RtContext *ctx, const float *seeds, uint32_t nFrames)
         const uint32_t fA = (ctx->optTwoStreams && f >= 2 && ctx->stream2) ? (f + 1) / 2 : f, fB = f - fA;
         if (fB) {
             // the second stream starts after the seeds are up (and, by stream order, after the last batch was folded in)
-            RT_HIP(ctx, hipEventRecord(ctx->evFork, ctx->stream));
-            RT_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->evFork, 0));
+            RT_HIP(ctx, hipEventRecord(ctx->evLane1Idle, ctx->stream));
+            RT_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->evLane1Idle, 0));
             {
-                RtLaneScope lane(ctx, ctx->stream2, fA, ctx->dQCount + CNT_WORDS);
+                // (2: a frame lane of its own -- masked streams, events, spill areas -- so that its shadow rays overlap its bounces too)
+                const bool ownLane = ctx->optTwoStreams == 2;
+                RtLaneScope lane(ctx, ctx->stream2, fA, ctx->dQCount + CNT_WORDS, ownLane ? 2u : 1u, ownLane);
                 rc = render_lane(ctx, fB, matte, shared);
             }
             if (rc) return rc;
-            RT_HIP(ctx, hipEventRecord(ctx->evJoin, ctx->stream2));
         }
         if ((rc = render_lane(ctx, fA, matte, shared))) return rc;
-        if (fB) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evJoin, 0));
+        if (fB) {
+            RT_HIP(ctx, hipEventRecord(ctx->evLane1Idle, ctx->stream2));
+            RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evLane1Idle, 0));
+        }
         ctx->lastFrame = f - 1;
         if ((rc = accumulate_frames(ctx, f, ctx->sampleCount, matte ? 1 : 0, 0))) return rc;
         ctx->sampleCount += f;
