@@ -77,10 +77,13 @@
 #define TRV_TRI_MIN_LANES 8u    // the triangle phase ends when fewer lanes than this still have triangles queued (0 = when none has; 0 / 8 / 16 / 24 / 32: 84.3 / 82.8 / 83.0 / 83.6 / 85.4 ms per image)
 #endif
 #ifndef TRV_SHARE_MIN_IDLE
-#define TRV_SHARE_MIN_IDLE 32u
+#define TRV_SHARE_MIN_IDLE 16u  // (32 / 16 / 8 with all pairs of a round handed over at once: 0.52 / 0.475 / 0.485 ms for 0.26 M camera rays, an eighth of the image 14.9 / 14.5 / 14.75 ms)
 #endif
 #ifndef TRV_SHARE_TRIPS
 #define TRV_SHARE_TRIPS 16u
+#endif
+#ifndef TRV_SHARE_ROUNDS
+#define TRV_SHARE_ROUNDS 3u     // levels a lane hands over per turn of the main loop, at most (1 / 3 / 6: 0.51 / 0.52 / 0.54 ms for 0.26 M camera rays, the whole image 90.5 / 89.7 / 90.8 ms)
 #endif
 #define TRV_DONE 0xFFFFFFFFu
 #define TRV_REDO 0xFFFFFFFEu    // in WalkState::tos of a lane whose node is TRV_DONE: this ray takes the exact, stackless walk next
@@ -679,41 +682,57 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
 #endif
         if (sharing && feed.exhausted) {
             shareTrips = TRV_SHARE_TRIPS;
-            const uint32_t lowest = share & 63u;
-            unsigned long long give = __ballot(hasRay && w.node != TRV_DONE && lowest + 2u <= w.sp && lowest < TRV_STACK_LDS);
-            unsigned long long take = __ballot(!hasRay);
-            if (give != 0ull && (uint32_t)__popcll(take) >= TRV_SHARE_MIN_IDLE) {
-                while (give != 0ull && take != 0ull) {
-                    const uint32_t D = (uint32_t)__ffsll((long long)give) - 1u, T = (uint32_t)__ffsll((long long)take) - 1u;   // wave-uniform
-                    give &= give - 1ull;
-                    take &= take - 1ull;
-                    const float gox = lane_value(o.x, D), goy = lane_value(o.y, D), goz = lane_value(o.z, D);
-                    const float gdx = lane_value(d.x, D), gdy = lane_value(d.y, D), gdz = lane_value(d.z, D);
-                    const float gt = lane_value(h.t, D), gu = lane_value(h.u, D), gv = lane_value(h.v, D);
-                    const uint32_t gleaf = lane_value(h.leaf, D), gfirst = lane_value(firstHit, D);
-                    const uint32_t level = lane_value(share, D) & 63u;
-                    if (lane == T) {
-                        o = rt_mk3(gox, goy, goz);
-                        d = rt_mk3(gdx, gdy, gdz);
-                        r = rt_mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                        slab = rt_ray_slab(sv.grid, o, r);
-                        h.t = gt; h.u = gu; h.v = gv; h.leaf = gleaf;
-                        firstHit = gfirst;
-                        uint32_t *entry = lds + level * TRV_THREADS + (threadIdx.x & ~63u) + D;
-                        w.node = *entry;
-                        *entry = TRV_DONE;
-                        stk[0] = TRV_DONE;
-                        w.sp = 1;
-                        w.tos = TRV_DONE;
-                        w.npend = 0;
-                        hasRay = true;
-                        share = 1u | (D << 16) | (1u << 24);
-                    }
-                    if (lane == D) share += 1u + (1u << 8);
-#ifdef TRV_SHARE_STATS
-                    shGiven++;
-#endif
+            // All pairs of a round at once: the r-th lane that gives with the r-th lane that takes.  Lane r learns which
+            // lane is the r-th giver (a forward permute: every giver sends its number to lane "its rank"; the others send
+            // to lane 63, which is the rank of no giver unless all 64 give, and then nobody else sends), a taker fetches its
+            // giver's ray and hit with backward permutes and the subtree from the giver's stack in LDS.  In a further
+            // round the givers hand over their next level, as long as lanes are left without a ray.
+            for (uint32_t round = 0; round < TRV_SHARE_ROUNDS; ++round) {
+                const uint32_t lowest = share & 63u;
+                const bool canGive = hasRay && w.node != TRV_DONE && lowest + 2u <= w.sp && lowest < TRV_STACK_LDS;
+                const unsigned long long give = __ballot(canGive), take = __ballot(!hasRay);
+                const uint32_t nTake = lane_count(take);
+                if (give == 0ull || nTake < (round == 0u ? TRV_SHARE_MIN_IDLE : 1u)) break;
+                const uint32_t gRank = (uint32_t)__popcll(give & lt), tRank = (uint32_t)__popcll(take & lt);
+                // (a lane number comes with bit 7 set: a lane that nobody sends to receives zero)
+                const uint32_t giverOfRank = (uint32_t)__builtin_amdgcn_ds_permute((int)((canGive ? gRank : 63u) << 2), (int)(canGive ? lane | 0x80u : 0u));
+                const uint32_t fromWord = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(tRank << 2), (int)giverOfRank);
+                const uint32_t from = fromWord & 63u;
+                const bool taking = !hasRay && (fromWord & 0x80u) != 0u, giving = canGive && gRank < nTake;
+                const int at = (int)(from << 2);
+                const float gox = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)__float_as_uint(o.x)));
+                const float goy = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)__float_as_uint(o.y)));
+                const float goz = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)__float_as_uint(o.z)));
+                const float gdx = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)__float_as_uint(d.x)));
+                const float gdy = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)__float_as_uint(d.y)));
+                const float gdz = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)__float_as_uint(d.z)));
+                const float gt = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)__float_as_uint(h.t)));
+                const float gu = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)__float_as_uint(h.u)));
+                const float gv = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)__float_as_uint(h.v)));
+                const uint32_t gleaf = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)h.leaf);
+                const uint32_t gfirst = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)firstHit);
+                const uint32_t level = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)share) & 63u;
+                if (taking) {
+                    o = rt_mk3(gox, goy, goz);
+                    d = rt_mk3(gdx, gdy, gdz);
+                    r = rt_mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    slab = rt_ray_slab(sv.grid, o, r);
+                    h.t = gt; h.u = gu; h.v = gv; h.leaf = gleaf;
+                    firstHit = gfirst;
+                    uint32_t *entry = lds + level * TRV_THREADS + (threadIdx.x & ~63u) + from;
+                    w.node = *entry;
+                    *entry = TRV_DONE;
+                    stk[0] = TRV_DONE;
+                    w.sp = 1;
+                    w.tos = TRV_DONE;
+                    w.npend = 0;
+                    hasRay = true;
+                    share = 1u | (from << 16) | (1u << 24);
                 }
+                if (giving) share += 1u + (1u << 8);
+#ifdef TRV_SHARE_STATS
+                shGiven += (unsigned long long)__popcll(__ballot(giving));
+#endif
             }
         }
         TRV_SHARE_CLK(0)
