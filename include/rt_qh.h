@@ -219,6 +219,38 @@ RT_HD bool rt_slab_maybe_octant_near(const RtRaySlab &s, uint32_t wx, uint32_t w
     return !sureMiss;
 }
 
+/* The same, and *shifted = max over the axes of (near value on the axis - back[axis]).  (For OCT = 8: any ray, near and
+ * far picked by min / max.)  A point of the ray within a distance rho of the box (on every axis: within rho of the
+ * box's extent) has, on each axis a, a ray parameter of at least near[a] - rho |d| / |d[a]| in units of the ray
+ * parameter; with back[a] that amount, *shifted is the smallest parameter at which the ray can be that near the box.
+ * With back = 0 it is the entry distance itself.  The near values are lower bounds already (the slab constants carry
+ * their margin). */
+template <uint32_t OCT>
+RT_HD bool rt_slab_maybe_shifted(const RtRaySlab &s, uint32_t wx, uint32_t wy, uint32_t wz, const float back[3], float *tnear, float *shifted)
+{
+    float nx, ny, nz, fx, fy, fz;
+    if (OCT < 8u) {
+        nx = (OCT & 1u) ? __builtin_fmaf(RT_QH_HI(wx), s.A[0], s.Bhi[0]) : __builtin_fmaf(RT_QH_LO(wx), s.A[0], s.Blo[0]);
+        fx = (OCT & 1u) ? __builtin_fmaf(RT_QH_LO(wx), s.A[0], s.Blo[0]) : __builtin_fmaf(RT_QH_HI(wx), s.A[0], s.Bhi[0]);
+        ny = (OCT & 2u) ? __builtin_fmaf(RT_QH_HI(wy), s.A[1], s.Bhi[1]) : __builtin_fmaf(RT_QH_LO(wy), s.A[1], s.Blo[1]);
+        fy = (OCT & 2u) ? __builtin_fmaf(RT_QH_LO(wy), s.A[1], s.Blo[1]) : __builtin_fmaf(RT_QH_HI(wy), s.A[1], s.Bhi[1]);
+        nz = (OCT & 4u) ? __builtin_fmaf(RT_QH_HI(wz), s.A[2], s.Bhi[2]) : __builtin_fmaf(RT_QH_LO(wz), s.A[2], s.Blo[2]);
+        fz = (OCT & 4u) ? __builtin_fmaf(RT_QH_LO(wz), s.A[2], s.Blo[2]) : __builtin_fmaf(RT_QH_HI(wz), s.A[2], s.Bhi[2]);
+    } else {
+        const float t1x = __builtin_fmaf(RT_QH_LO(wx), s.A[0], s.Blo[0]), t2x = __builtin_fmaf(RT_QH_HI(wx), s.A[0], s.Bhi[0]);
+        const float t1y = __builtin_fmaf(RT_QH_LO(wy), s.A[1], s.Blo[1]), t2y = __builtin_fmaf(RT_QH_HI(wy), s.A[1], s.Bhi[1]);
+        const float t1z = __builtin_fmaf(RT_QH_LO(wz), s.A[2], s.Blo[2]), t2z = __builtin_fmaf(RT_QH_HI(wz), s.A[2], s.Bhi[2]);
+        nx = __builtin_fminf(t1x, t2x); fx = __builtin_fmaxf(t1x, t2x);
+        ny = __builtin_fminf(t1y, t2y); fy = __builtin_fmaxf(t1y, t2y);
+        nz = __builtin_fminf(t1z, t2z); fz = __builtin_fmaxf(t1z, t2z);
+    }
+    const float tn = __builtin_fmaxf(nx, __builtin_fmaxf(ny, nz));
+    const float tf = __builtin_fminf(fx, __builtin_fminf(fy, fz));
+    *tnear = tn;
+    *shifted = __builtin_fmaxf(nx - back[0], __builtin_fmaxf(ny - back[1], nz - back[2]));
+    return !(tn > tf || tf < 0.0f);
+}
+
 template <uint32_t OCT>
 RT_HD bool rt_slab_maybe_octant(const RtRaySlab &s, uint32_t wx, uint32_t wy, uint32_t wz)
 {

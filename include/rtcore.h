@@ -407,7 +407,7 @@ int rt_post_bloom(RtContext *ctx, int src, const RtBloomParams *params);
 int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
 
 /* ------------------------------------------------------------------ tuning */
-/* Execution knobs; none changes a result bit, except RT_OPT_PRUNE_BY_DISTANCE as said there.  No reference
+/* Execution knobs; none changes a result bit, except value 2 of RT_OPT_PRUNE_BY_DISTANCE as said there.  No reference
  * counterpart (the reference has one fixed schedule: a thread per pixel, a dispatch per frame).
  *   RT_OPT_PACKET_SHADOW   0 (default): 1 = the 16 soft-shadow rays of a pixel walk the tree as one packet
  *   RT_OPT_PACKET_PRIMARY  0 (default): 1 = camera rays walk the tree in packets of 16 neighbouring pixels
@@ -445,26 +445,31 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *                          rt_dispatch_shadowmap traces its own primary rays as it does with the option off or while
  *                          counters are enabled (the work counters keep the two kernels apart).  Between the two calls
  *                          RT_IMAGE_SHADOWMAP is half written: read it after rt_dispatch_shadowmap, as the reference does.
- *   RT_OPT_PRUNE_BY_DISTANCE  THE ONE KNOB THAT CAN CHANGE A RESULT.  A ray that uses the rule does not enter a box that begins
- *                          more than 1/64 beyond the closest hit it holds.  The reference enters every box the ray passes
- *                          (BVHRayTracing.cginc:87-123 has no distance test) and keeps the hit with the smallest COMPUTED
- *                          distance.  A triangle in a box left out lies behind the hit already held, so the hit returned is the
- *                          same -- as far as Moller-Trumbore's distance of that triangle is not far in front of the
- *                          triangle's own box.  Float32 does not promise that for a ray nearly inside the triangle's plane:
- *                          distance, u and v are all divided by det = e1 . (d x e2), the small difference of large products,
- *                          whose relative error is about 6e-8 / (angle between ray and plane x sine of the angle between the
- *                          edges): beyond the 1/64 of room within 4e-6 rad of a well-shaped triangle, within 4e-4 rad of a
- *                          sliver with edges 0.6 degrees apart, and no wider margin is safe for every triangle.  The CPU
- *                          checker's model of the rule loses 13 hits in a million on a scene built for it
- *                          (tests/adversarial.py, tests/test_oracle_cpu.py); on every scene of ordinary shapes, and on that
- *                          one through the kernels, all values give the same bits (tests/test_gpu_prune.py).  Values:
- *                            0  no ray uses the rule: the reference's walk, box for box
- *                            1  (default) the rays whose hits reach the caller only as radiance use it -- the bounce rays of
- *                               CSMain from the second segment on, the 16 soft-shadow rays of a ShadowMap pixel; the rays
- *                               whose first hits are handed out triangle by triangle do not: rt_trace_rays*, camera rays
- *                               (CSMain's first segment, the ShadowMap kernel's primary ray).  Their work counters
- *                               (rt_enable_counters) equal the CPU checker's
- *                            2  every ray uses it (the 10 M-triangle stress launch: 31 instead of 106 ms)
+ *   RT_OPT_PRUNE_BY_DISTANCE  Which boxes a ray may leave out because they begin beyond the closest hit it holds.  The
+ *                          reference enters every box the ray passes (BVHRayTracing.cginc:87-123 has no distance test) and
+ *                          keeps the hit with the smallest COMPUTED distance, so a box may be left out only if no triangle
+ *                          in it can be computed nearer than the hit already held -- and the distance Moller-Trumbore
+ *                          computes in float32 for a ray nearly inside a triangle's plane can lie far in front of the
+ *                          triangle: distance, u and v are all divided by det = e1 . (d x e2), the small difference of
+ *                          large products.  Values:
+ *                            0  no box is left out: the reference's walk, box for box (the work counters of
+ *                               rt_enable_counters then equal the CPU checker's)
+ *                            1  (default) the bounded rule, the same hits as 0 bit for bit.  The reference's own cut
+ *                               (IntersectTriangle_MT97 drops det < 1e-8) bounds how far a computed distance can be off:
+ *                               by 192 |e1||e2| |o - v0| at most.  For triangles that are SMALL (|e1||e2| <= 2^-12 and
+ *                               |e1| + |e2| <= 1/4 in scene units -- like the cut, an absolute measure) that is a few per
+ *                               cent of the distance, and a box is left out when the plane through its nearest corner at
+ *                               right angles to the ray lies beyond the closest hit by more than that (derivation in
+ *                               csrc/rt_traverse.h, "leaving out boxes, with a bound").  Boxes that hold a large triangle
+ *                               are never left out; a scene of large triangles only is walked as with 0.  Used by camera
+ *                               rays, rt_trace_rays* and bounce rays; shadow rays leave out nothing (they end at a first
+ *                               hit where that settles the answer, RT_OPT_FIRST_HIT_SHADOW)
+ *                            2  every ray leaves out what begins more than 1/64 beyond its closest hit, large triangles
+ *                               or not: NOT the reference's result where a computed distance is that far off (within
+ *                               4e-6 rad of a well-shaped triangle's plane, 4e-4 rad of a sliver's; the CPU checker's
+ *                               model of the rule loses 13 hits in a million on a scene built for it,
+ *                               tests/adversarial.py, tests/test_oracle_cpu.py).  The 10 M-triangle stress launch, all
+ *                               large triangles: 32 instead of 106 ms
  *   RT_OPT_SHARE_LONG_WALKS 1 (default): a walker launch lasts as long as its longest ray, a chain of dependent fetches
  *                          that can run to thousands of steps.  Once a launch has no rays left to deal, lanes of a wave
  *                          that have run out of rays take over stacked subtrees of the lanes that are still walking

@@ -587,6 +587,7 @@ struct BuildPlan {
     RtKeyPlan keys;
     RtQGrid grid;
     RtAABB root;
+    uint32_t smallEdgeProduct, smallEdgeSum;     // float bits: the largest among the small triangles (k_pack_leaves)
 };
 
 __global__ void k_plan(const float4 *__restrict__ bvhData, BuildPlan *__restrict__ out)
@@ -602,6 +603,8 @@ __global__ void k_plan(const float4 *__restrict__ bvhData, BuildPlan *__restrict
         p.root.min[a] = lo[a];
         p.root.max[a] = hi[a];
     }
+    p.smallEdgeProduct = 0u;
+    p.smallEdgeSum = 0u;
     *out = p;
 }
 
@@ -629,7 +632,9 @@ __global__ __launch_bounds__(256) void k_emit_qnodes(uint32_t N, const BuildPlan
 
 // Two levels per record: the places of node i hold the children of its left child, then of its right child; a child
 // that is a leaf takes one place as itself.  Boxes and references are copied from the finished 32-byte nodes.
-__global__ __launch_bounds__(256) void k_emit_wide_nodes(uint32_t NI, const uint4 *__restrict__ qnodes, uint4 *__restrict__ wnodes)
+// large: per leaf / per node, "is (holds) a large triangle" -- carried in bit 30 of the references.
+__global__ __launch_bounds__(256) void k_emit_wide_nodes(uint32_t NI, const uint4 *__restrict__ qnodes, uint4 *__restrict__ wnodes,
+                                                          const uint32_t *__restrict__ leafLarge, const uint32_t *__restrict__ nodeLarge)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= NI) return;
@@ -653,6 +658,8 @@ __global__ __launch_bounds__(256) void k_emit_wide_nodes(uint32_t NI, const uint
             ref[n++] = gb.w;
         }
     }
+    for (int k = 0; k < 4; ++k)
+        if (ref[k] != RT_INVALID && ((ref[k] & RT_LEAF_BIT) ? leafLarge[ref[k] & ~RT_LEAF_BIT] : nodeLarge[ref[k]]) != 0u) ref[k] |= RT_REF_LARGE;
     wnodes[i * 4 + 0] = make_uint4(box[0][0], box[0][1], box[0][2], box[1][0]);
     wnodes[i * 4 + 1] = make_uint4(box[1][1], box[1][2], box[2][0], box[2][1]);
     wnodes[i * 4 + 2] = make_uint4(box[2][2], box[3][0], box[3][1], box[3][2]);
@@ -664,10 +671,12 @@ __global__ __launch_bounds__(256) void k_pack_leaves(uint32_t N, const uint32_t 
                                                       const uint32_t *__restrict__ idx, const float *__restrict__ verts,
                                                       const uint32_t *__restrict__ matIdx, const int32_t *__restrict__ shadow,
                                                       const float4 *__restrict__ triAABB, float4 *__restrict__ leafTri,
-                                                      float4 *__restrict__ leafShade)
+                                                      float4 *__restrict__ leafShade, uint32_t *__restrict__ leafLarge, BuildPlan *plan)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= N) return;
+    // (leafLarge, plan: the leaf's class for the bounded rule and the two maxima over the small ones; nullptr: not wanted)
+    float product = 0.0f, sum = 0.0f;
+    if (j < N) {
     const uint32_t t = sortedIdx[j];
     const float4 bmn = triAABB[t * 2], bmx = triAABB[t * 2 + 1];
     const uint32_t i0 = idx[t * 3 + 0], i1 = idx[t * 3 + 1], i2 = idx[t * 3 + 2];
@@ -682,6 +691,45 @@ __global__ __launch_bounds__(256) void k_pack_leaves(uint32_t N, const uint32_t 
     leafShade[j * 3 + 0] = make_float4(a[3], a[4], a[5], b[3]);
     leafShade[j * 3 + 1] = make_float4(b[4], b[5], c[3], c[4]);
     leafShade[j * 3 + 2] = make_float4(c[5], __uint_as_float(matIdx[t]), __int_as_float(shadow[t * 2 + 0]), 0.0f);
+    if (leafLarge) {
+        // rounded up generously (2^-20 relative): the bound they go into has to hold for the exact lengths
+        const float l1 = rt_sqrt(rt_dot3(e1, e1)) * 1.000001f, l2 = rt_sqrt(rt_dot3(e2, e2)) * 1.000001f;
+        product = l1 * l2 * 1.000001f;
+        sum = (l1 + l2) * 1.000001f;
+        const bool small = product <= RT_SMALL_EDGE_PRODUCT && sum <= RT_SMALL_EDGE_SUM;     // (false for NaN)
+        leafLarge[j] = small ? 0u : 1u;
+        if (!small) product = sum = 0.0f;
+    }
+    }
+    if (plan) {        // one atomic pair per wave
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            product = rt_max(product, __shfl_down(product, off, 64));
+            sum = rt_max(sum, __shfl_down(sum, off, 64));
+        }
+        if ((threadIdx.x & 63u) == 0u && product > 0.0f) {
+            atomicMax(&plan->smallEdgeProduct, __float_as_uint(product));
+            atomicMax(&plan->smallEdgeSum, __float_as_uint(sum));
+        }
+    }
+}
+
+// Every node on the way from a large triangle to the root holds one: a thread per node looks at its two children and,
+// where one is a large leaf, marks the node and its ancestors (plain stores of the same value from whoever gets there).
+__global__ __launch_bounds__(256) void k_mark_large(uint32_t NI, const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
+                                                     const uint32_t *__restrict__ parent, const uint32_t *__restrict__ leafLarge,
+                                                     uint32_t *nodeLarge)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NI) return;
+    const uint32_t l = left[i], r = right[i];
+    const bool any = ((l & RT_LEAF_BIT) && leafLarge[l & ~RT_LEAF_BIT]) || ((r & RT_LEAF_BIT) && leafLarge[r & ~RT_LEAF_BIT]);
+    if (!any) return;
+    uint32_t at = i;
+    for (uint32_t guard = 0; guard < 4096u && at != 0xFFFFFFFFu; ++guard) {
+        nodeLarge[at] = 1u;
+        at = parent[at];
+    }
 }
 
 // ------------------------------------------------------------------ wire-struct readback kernels
@@ -956,6 +1004,8 @@ int rt_build_impl(RtContext *ctx)
     const uint32_t N = ctx->N;
     rt_free_build(ctx);
     memset(&ctx->rootBox, 0, sizeof ctx->rootBox);
+    ctx->smallEdgeProduct = ctx->smallEdgeSum = 0.0f;
+    if (N >= RT_REF_INDEX) return rt_fail(ctx, RT_E_INVALID, "BVH build: at most 2^30 - 2 triangles");
     if (N == 0) {
         ctx->built = true;
         return RT_OK;
@@ -1043,14 +1093,18 @@ int rt_build_impl(RtContext *ctx)
         // its boxes and the rotation passes (a rotation can lengthen a path by a level: PASS_LEVELS leaves room for that)
         hipLaunchKernelGGL(k_gather_leaf_boxes, gridN, blk, 0, st, N, wSortedIdx, (const float4 *)ctx->dTriAABB, wLeafBox);
         if ((rc = run_sweep(ctx, sc, NI, N >= 3 ? 1u + RT_ROTATION_PASSES : 1u, wLeft, wRight, wParent, wLeafBox, wBvhData))) return rc;
+        // leaf records first: they say which triangles are large, and the two-level records carry that in their references
+        rt_timer_begin(ctx, "k_pack_leaves");
+        uint32_t *leafLarge = sc.keysB, *nodeLarge = sc.done;       // (scratch that the sorts and the sweep are done with)
+        hipLaunchKernelGGL(k_pack_leaves, gridN, blk, 0, st, N, wSortedIdx, ctx->dIdx, (const float *)ctx->dVerts, ctx->dMatIdx, ctx->dShadow,
+                           (const float4 *)ctx->dTriAABB, (float4 *)ctx->dLeafTri, (float4 *)ctx->dLeafShade, leafLarge, plan);
+        rt_timer_end(ctx);
+        RT_HIP(ctx, hipMemsetAsync(nodeLarge, 0, (size_t)NI * 4, st));
         rt_timer_begin(ctx, "k_emit_qnodes");
+        hipLaunchKernelGGL(k_mark_large, gridNI, blk, 0, st, NI, wLeft, wRight, wParent, leafLarge, nodeLarge);
         hipLaunchKernelGGL(k_emit_qnodes, gridNI, blk, 0, st, N, plan, wLeft, wRight, wLeafBox,
                            (const float4 *)wBvhData, (uint4 *)ctx->dQNodes, ctx->dErrorFlag);
-        hipLaunchKernelGGL(k_emit_wide_nodes, gridNI, blk, 0, st, NI, (const uint4 *)ctx->dQNodes, (uint4 *)ctx->dWNodes);
-        rt_timer_end(ctx);
-        rt_timer_begin(ctx, "k_pack_leaves");
-        hipLaunchKernelGGL(k_pack_leaves, gridN, blk, 0, st, N, wSortedIdx, ctx->dIdx, (const float *)ctx->dVerts, ctx->dMatIdx, ctx->dShadow,
-                           (const float4 *)ctx->dTriAABB, (float4 *)ctx->dLeafTri, (float4 *)ctx->dLeafShade);
+        hipLaunchKernelGGL(k_emit_wide_nodes, gridNI, blk, 0, st, NI, (const uint4 *)ctx->dQNodes, (uint4 *)ctx->dWNodes, leafLarge, nodeLarge);
         rt_timer_end(ctx);
         // ---- tie the two together: visiting rank per leaf, leaf numbers in the reference tree's exact nodes
         rt_timer_begin(ctx, "k_visit_rank");
@@ -1063,7 +1117,7 @@ int rt_build_impl(RtContext *ctx)
         // a single triangle: no internal node, nothing can be hit (bvhData[0] is the zero box); records in input order
         rt_timer_begin(ctx, "k_pack_leaves");
         hipLaunchKernelGGL(k_pack_leaves, gridN, blk, 0, st, N, ctx->dSortedIdx, ctx->dIdx, (const float *)ctx->dVerts, ctx->dMatIdx, ctx->dShadow,
-                           (const float4 *)ctx->dTriAABB, (float4 *)ctx->dLeafTri, (float4 *)ctx->dLeafShade);
+                           (const float4 *)ctx->dTriAABB, (float4 *)ctx->dLeafTri, (float4 *)ctx->dLeafShade, nullptr, nullptr);
         rt_timer_end(ctx);
         RT_HIP(ctx, hipMemsetAsync(ctx->dLeafRank, 0, (size_t)N * 4, st));
     }
@@ -1077,6 +1131,8 @@ int rt_build_impl(RtContext *ctx)
     if (N >= 2) {
         ctx->rootBox = hostPlan.root;
         ctx->grid = hostPlan.grid;
+        memcpy(&ctx->smallEdgeProduct, &hostPlan.smallEdgeProduct, 4);
+        memcpy(&ctx->smallEdgeSum, &hostPlan.smallEdgeSum, 4);
     }
     RT_HIP(ctx, hipGetLastError());
     for (uint32_t k = 0; k < sc.nFinal; ++k)

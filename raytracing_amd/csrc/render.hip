@@ -695,7 +695,7 @@ int rt_debug_eval_impl(RtContext *ctx, int which, const float *dx, const float *
 }
 
 // ------------------------------------------------------------------ host side
-RtSceneView rt_scene_view(RtContext *ctx, bool firstHitsHandedOut)
+RtSceneView rt_scene_view(RtContext *ctx)
 {
     RtSceneView sv;
     memset(&sv, 0, sizeof sv);
@@ -720,9 +720,15 @@ RtSceneView rt_scene_view(RtContext *ctx, bool firstHitsHandedOut)
     // walker launches that may be on the chip together spill into different areas
     sv.stackSpill = ctx->dStackSpill + (size_t)ctx->spillArea * ctx->numCU * RT_SPILL_WORDS_PER_CU;
     sv.errorFlag = ctx->dErrorFlag;
-    // Camera rays and caller rays walk every box they pass unless told otherwise: theirs are the hits a caller sees
-    // triangle by triangle, and leaving boxes out can change a hit where Moller-Trumbore's distance is far off (rtcore.h)
-    sv.pruneScale = ctx->optPruneByDistance >= (firstHitsHandedOut ? 2 : 1) ? RT_PRUNE_SCALE : rt_inf();
+    // RT_OPT_PRUNE_BY_DISTANCE: 0 no box is left out.  1 (the default) camera, caller and bounce rays leave out what the
+    // bounded rule allows (rt_traverse.h: the same hits as with 0, by the bound; it needs the two-level records, which carry
+    // the flags of the large triangles, and a scene with small triangles), shadow rays leave out nothing (they stop at a
+    // first hit where that settles the answer, which is exact as well).  2 every ray leaves out what begins more than 1.5 %
+    // beyond its closest hit: faster, and not the reference's result where Moller-Trumbore's distance is far off (rtcore.h).
+    const int opt = ctx->optPruneByDistance;
+    sv.pruneScale = opt == 2 ? RT_PRUNE_SCALE : rt_inf();
+    sv.boundQ = opt == 1 && ctx->smallEdgeProduct > 0.0f && ctx->optWideNodes ? RT_BOUND_C * ctx->smallEdgeProduct : 0.0f;
+    sv.boundE = ctx->smallEdgeSum;
     sv.shareWalks = ctx->optShareLongWalks ? 1u : 0u;
     return sv;
 }
@@ -1106,7 +1112,7 @@ static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup
     if (n == 0) return RT_OK;
     const uint32_t total = n * frames;
     hipStream_t st = ctx->stream;
-    const RtSceneView sv = rt_scene_view(ctx), svCamera = rt_scene_view(ctx, true);
+    const RtSceneView sv = rt_scene_view(ctx);
     const bool brute = (ctx->params.flags & RT_FLAG_BRUTE_FORCE) != 0;
     const dim3 blk(Q_THREADS), grid((total + Q_TILE - 1) / Q_TILE);
     RT_HIP(ctx, hipMemsetAsync(ctx->dQCount, 0, CNT_WORDS * sizeof(uint32_t), st));
@@ -1125,7 +1131,7 @@ static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup
             hipLaunchKernelGGL(k_brute_extend<QueueSrc>, dim3((total + 255) / 256), dim3(256), 0, st, ctx->brute, src, ctx->countersOn ? ctx->dStats : nullptr);
             rt_timer_end(ctx);
         } else if (b == 0 && ctx->optPacketPrimary) launch_traverse_packets(ctx, sv, src, ctx->dQCount + CNT_CURSOR(b), total, "k_extend");
-        else launch_traverse(ctx, b == 0 ? svCamera : sv, src, ctx->dQCount + CNT_CURSOR(b), total, "k_extend");
+        else launch_traverse(ctx, sv, src, ctx->dQCount + CNT_CURSOR(b), total, "k_extend");
         if (b == 0 && withShadowSetup) launch_sm_setup(ctx, sv, total, qin, ctx->dQCount);   // before shade moves the rays on
         if (b == overlapAfter) {
             const int rc = overlap_fork(ctx, sv, total);
@@ -1170,7 +1176,7 @@ static int shadowmap_frames(RtContext *ctx, uint32_t frames)
     prim.qcount = cnt + CNT_SMPRIM;
     prim.hit = ctx->dHit;
     if (ctx->optPacketPrimary) launch_traverse_packets(ctx, sv, prim, cnt + CNT_FETCH_SM0, total, "k_extend");
-    else launch_traverse(ctx, rt_scene_view(ctx, true), prim, cnt + CNT_FETCH_SM0, total, "k_extend");
+    else launch_traverse(ctx, rt_scene_view(ctx), prim, cnt + CNT_FETCH_SM0, total, "k_extend");
     launch_sm_setup(ctx, sv, total, ctx->dRay[0], cnt + CNT_SMPRIM);
     launch_shadow_rays(ctx, sv, total);
     RT_HIP(ctx, hipGetLastError());
@@ -1460,7 +1466,7 @@ int rt_readback_async_impl(RtContext *ctx, const float4 *src, float *pinnedDst)
 int rt_trace_device_impl(RtContext *ctx, const float4 *o, const float4 *d, uint32_t n, RtHitRec *hits)
 {
     if (n == 0) return RT_OK;
-    const RtSceneView sv = rt_scene_view(ctx, true);
+    const RtSceneView sv = rt_scene_view(ctx);
     RT_HIP(ctx, hipMemsetAsync(ctx->dQCount + CNT_FETCH_TRACE, 0, sizeof(uint32_t), ctx->stream));
     ArraySrc src;
     src.org = o;
@@ -1514,7 +1520,7 @@ int rt_trace_device_static_impl(RtContext *ctx, const float4 *o, const float4 *d
     }
     if (!ptr) return rt_fail(ctx, RT_E_STATE, "no static scratch array on device %d", ctx->device);
     if (n == 0) return RT_OK;
-    RtSceneView sv = rt_scene_view(ctx, true);
+    RtSceneView sv = rt_scene_view(ctx);
     sv.stats = nullptr;
     sv.errorFlag = ptr + 32;
     sv.stackSpill = ptr + RT_STATIC_HEAD_WORDS;

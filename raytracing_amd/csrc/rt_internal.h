@@ -95,6 +95,8 @@ struct RtSceneView {
     uint32_t cubeSize;
     uint32_t *stackSpill;      // deep stack levels of the one-ray-per-lane walker
     float pruneScale;          // a box whose entry distance exceeds (closest hit so far) x this is not entered; +inf: none is left out
+    float boundQ;              // the bounded rule (rt_traverse.h, "leaving out boxes, with a bound"): RT_BOUND_C x the largest
+    float boundE;              //   edge product of the scene's small triangles, and their largest edge sum; boundQ = 0: rule off
     uint32_t shareWalks;       // non-zero: at the end of a launch idle lanes take over stacked subtrees of lanes that still walk
     unsigned long long *stats; // 8 counters or nullptr
     uint32_t *errorFlag;
@@ -194,6 +196,17 @@ struct RtPendingEvent {
 #define RT_COUNTER_BLOCK_WORDS 1536 // queue counts and ray cursors (dQCount), a 128-byte line each, one set per stream
 #define RT_SPILL_WORDS_PER_CU (2048 * RT_STACK_DEPTH)   // room for every stack level of 2048 lanes per CU
 #define RT_NONCASTER_LIST 8                             // non-casting triangles a shadow ray is tested against one by one
+// A reference to a child in a two-level record (RtQNode4): bit 31 leaf, bit 30 "the subtree holds a large triangle" (the bounded
+// rule never leaves such a box out), the rest the number of the node or leaf.
+#define RT_REF_LARGE 0x40000000u
+#define RT_REF_INDEX 0x3FFFFFFFu
+// Triangles the bounded rule counts as small: edge product |e1||e2| and edge sum |e1| + |e2| at most these (scene units:
+// the reference's own cut, determinant < 1e-8, is absolute too).
+#define RT_SMALL_EDGE_PRODUCT 2.44140625e-4f    /* 2^-12 */
+#define RT_SMALL_EDGE_SUM 0.25f
+// the point o + t'd of a triangle the reference accepts lies within RT_BOUND_C x |e1||e2| x |o - v0| x |d| of the triangle
+// (derivation in rt_traverse.h: 28.9 unit roundoffs over the reference's smallest determinant, 1e-8, is 172.3)
+#define RT_BOUND_C 192.0f
 #define RT_SPILL_AREAS 4                                // walker launches that may be on the chip together: per frame lane (two), the
                                                         // launches of its own stream and the shadow-ray launch that overlaps them
 
@@ -285,7 +298,8 @@ struct RtContext {
     bool optCasterBox = true;             // shadow rays that cannot meet a shadow caster are not walked
     bool optFirstHitShadow = true;        // shadow rays that cannot meet a non-casting triangle stop at their first hit
     bool optOverlapShadow = true;         // walk the shadow rays while the later bounces run (render.hip, overlap_fork)
-    int optPruneByDistance = 1;           // RT_OPT_PRUNE_BY_DISTANCE: boxes beyond the closest hit found so far are not entered by 0 no ray, 1 the rays
+    int optPruneByDistance = 1;
+    float smallEdgeProduct = 0.0f, smallEdgeSum = 0.0f;   // largest |e1||e2| and |e1| + |e2| among the scene's small triangles (0: none)           // RT_OPT_PRUNE_BY_DISTANCE: boxes beyond the closest hit found so far are not entered by 0 no ray, 1 the rays
                                           // whose hits are not handed out (bounce rays, soft-shadow rays), 2 every ray
     bool optShareLongWalks = true;        // idle lanes take over parts of the walks a launch ends with (RT_OPT_SHARE_LONG_WALKS)
     bool optEagerShadowMap = true;        // rt_dispatch starts the ShadowMap pass of its frame (render.hip, rt_dispatch_impl)
@@ -355,8 +369,7 @@ int rt_readback_bvh_impl(RtContext *ctx, uint32_t *morton, uint32_t *sortedIdx, 
 void rt_free_build(RtContext *ctx);
 
 // render.hip
-// firstHitsHandedOut: the launch walks rays whose hits the caller gets to see, triangle by triangle (camera rays, rt_trace_rays*)
-RtSceneView rt_scene_view(RtContext *ctx, bool firstHitsHandedOut = false);
+RtSceneView rt_scene_view(RtContext *ctx);
 int rt_alloc_render(RtContext *ctx);
 // What a call borrows and gives back when it ends, however it ends (every error path returns early): scratch
 // buffers and events.  The stream is drained first, because launches in flight may still use the buffers.

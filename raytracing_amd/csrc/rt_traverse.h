@@ -7,10 +7,11 @@
 // is tested when its own box passes, the closest hit wins with strict '<', so
 // on equal distances the triangle met first in the reference's depth-first
 // order (left leaf, right leaf, right subtree, left subtree) is kept.
-// One option departs from "every box the ray passes": launches whose scene view carries a finite pruneScale
-// (RT_OPT_PRUNE_BY_DISTANCE: by default the bounce and soft-shadow rays, never the rays whose hits are handed out)
-// leave out boxes that begin beyond the closest hit held -- the same hit except where Moller-Trumbore's distance of
-// a triangle is far off (rtcore.h says when); with pruneScale = +inf the walk below is exact by construction.
+// Boxes may be left out of that walk where it is certain that nothing in them can be computed nearer than the hit
+// already held (RT_OPT_PRUNE_BY_DISTANCE 1, the default: traverse_rays, "leaving out boxes, with a bound") -- the result
+// stays the reference's bit for bit.  One option value departs from it: with 2 (a finite pruneScale in the scene view)
+// every box that begins 1.5 % beyond the closest hit is left out, the same hit except where Moller-Trumbore's distance
+// of a triangle is far off (rtcore.h says when).
 //
 // What is different is only HOW the same result is computed:
 //   * Inner nodes are a filter, not a decision.  With finite, non-zero direction
@@ -64,11 +65,10 @@
 #define TRV_WALK_NUM 1u         // leave the node phase when fewer than NUM/DEN of the lanes that still have nodes to visit
 #define TRV_WALK_DEN 2u         // can go on (the rest wait for triangle tests); 3/4, 3/5, 1/2, 2/5, 1/3 with two levels per step: 87.7 / 85.8 / 85.1 / 85.3 / 86.8 ms per image
 #endif
-// Boxes that begin beyond the closest hit a ray holds are not entered by the launches that use the rule
-// (RT_OPT_PRUNE_BY_DISTANCE): "beyond" with this much room, because the distance of a hit (Moller-Trumbore) and the
-// entry distance of a box (slab test) are two different float computations and only agree to rounding -- to rounding
-// of a quotient whose divisor can be nearly all rounding error (a ray nearly in a triangle's plane), which is why
-// the rule is not applied to rays whose hits are handed out.
+// RT_OPT_PRUNE_BY_DISTANCE 2: boxes that begin beyond the closest hit a ray holds are not entered, "beyond" with this much
+// room, because the distance of a hit (Moller-Trumbore) and the entry distance of a box (slab test) are two different
+// float computations and only agree to rounding -- to rounding of a quotient whose divisor can be nearly all rounding
+// error (a ray nearly in a triangle's plane), which is why this is an option and the default is the rule with a bound.
 #define RT_PRUNE_SCALE 1.015625f
 // Long walks are shared out at the end of a launch (RT_OPT_SHARE_LONG_WALKS, traverse_rays): once the launch has no
 // more rays to deal and at least this many lanes of a wave are idle, idle lanes take over stacked subtrees of lanes that
@@ -467,13 +467,21 @@ __device__ __forceinline__ void node_phase(const RtSceneView &sv, const RtRaySla
 // may pass and stacks the others.  Same stack as node_phase (level 0 holds TRV_DONE, entries are node numbers of the
 // same tree), without the register copy of its top; same end test; same results, because inner nodes are only a filter
 // (a box that is not tested -- the child's, between a node and its grandchildren -- cannot lose a triangle).
-template <uint32_t OCT, bool ORDERED>
-__device__ __forceinline__ bool wide_box(const RtRaySlab &slab, uint32_t wx, uint32_t wy, uint32_t wz, uint32_t ref, const float limit, float *tnear)
+template <uint32_t OCT, bool ORDERED, bool BOUNDED>
+__device__ __forceinline__ bool wide_box(const RtRaySlab &slab, uint32_t wx, uint32_t wy, uint32_t wz, uint32_t ref, const float limit, const float bw[3], const uint32_t largeBit, float *tnear)
 {
-    const bool maybe = OCT < 8u ? rt_slab_maybe_octant_near<(OCT & 7u)>(slab, wx, wy, wz, tnear) : rt_slab_maybe_near(slab, wx, wy, wz, tnear);
     // an unused place holds a box whose low planes lie above its high planes: the octant test never passes it for a ray
     // that is walked here (rt_slab_rejects_empty_box, checked when the ray is dealt), the test that sorts a slab's two
     // planes would
+    if (BOUNDED) {
+        // the bounded rule: what is compared with the limit is the smallest ray parameter at which the ray can be within
+        // the rule's distance of the box (bw: that distance per axis, in units of the ray parameter), and a box that holds
+        // a large triangle is never left out
+        float shifted;
+        const bool maybe = rt_slab_maybe_shifted<OCT>(slab, wx, wy, wz, bw, tnear, &shifted);
+        return maybe && (!(shifted > limit) || (ref & largeBit) != 0u) && (OCT < 8u || ref != RT_INVALID);
+    }
+    const bool maybe = OCT < 8u ? rt_slab_maybe_octant_near<(OCT & 7u)>(slab, wx, wy, wz, tnear) : rt_slab_maybe_near(slab, wx, wy, wz, tnear);
     return maybe && (!ORDERED || *tnear <= limit) && (OCT < 8u || ref != RT_INVALID);
 }
 
@@ -482,11 +490,17 @@ __device__ __forceinline__ bool wide_box(const RtRaySlab &slab, uint32_t wx, uin
 // passes and ends only when all are visited (limit = +inf, no stop at a first hit) gains nothing from an order: without
 // it the step goes on with the first place that is to be visited and stacks the others as they come, no distances
 // sorted (a quarter of the step's vector instructions).
-template <uint32_t OCT, bool COUNT, bool ORDERED>
+// BOUNDED (with ORDERED): boxes are left out by the bounded rule (traverse_rays, "leaving out boxes, with a bound"):
+// `limit` is the closest hit's distance and bw the rule's distance per axis (or, for the 1.5 % rule: the hit's distance
+// with that room, and zero).
+template <uint32_t OCT, bool COUNT, bool ORDERED, bool BOUNDED = false>
 __device__ __forceinline__ void node_phase_wide(const RtSceneView &sv, const RtRaySlab &slab, WalkState &w, uint32_t *stk, uint32_t *pend,
                                                 uint32_t *spill, const uint32_t spillLanes, uint32_t cnt[3], const bool feedExhausted, const float limit,
-                                                const uint32_t shareTrips)
+                                                const uint32_t shareTrips, const float bw0 = 0.0f, const float bw1 = 0.0f, const float bw2 = 0.0f,
+                                                const uint32_t largeBit = RT_REF_LARGE)
 {
+    // (largeBit: RT_REF_LARGE, or 0 where the 1.5 % rule goes through this phase: that rule knows no large triangles)
+    const float bw[3] = {bw0, bw1, bw2};
     uint32_t trips = 0;
     for (;;) {
         const bool busy = w.node != TRV_DONE, room = w.npend + 4u <= TRV_PEND_CAP;
@@ -497,15 +511,15 @@ __device__ __forceinline__ void node_phase_wide(const RtSceneView &sv, const RtR
         if (nAct == 0u || nAct * TRV_WALK_DEN < nBusy * TRV_WALK_NUM || (!feedExhausted && nBusy < 64u - TRV_REFILL_MIN)) break;
         if (nBusy <= 64u - TRV_SHARE_MIN_IDLE && ++trips > shareTrips) break;
         if (act) {
-            const uint4 *np = (const uint4 *)(sv.wnodes + w.node);
+            const uint4 *np = (const uint4 *)(sv.wnodes + (w.node & RT_REF_INDEX));     // (a reference may carry RT_REF_LARGE)
             const uint4 qa = np[0], qb = np[1], qc = np[2], qd = np[3];
             const uint32_t r0 = qd.x, r1 = qd.y, r2 = qd.z, r3 = qd.w;
             if (COUNT) cnt[0] += (r0 != RT_INVALID ? 1u : 0u) + (r1 != RT_INVALID ? 1u : 0u) + (r2 != RT_INVALID ? 1u : 0u) + (r3 != RT_INVALID ? 1u : 0u);
             float n0, n1, n2, n3;
-            const bool h0 = wide_box<OCT, ORDERED>(slab, qa.x, qa.y, qa.z, r0, limit, &n0);
-            const bool h1 = wide_box<OCT, ORDERED>(slab, qa.w, qb.x, qb.y, r1, limit, &n1);
-            const bool h2 = wide_box<OCT, ORDERED>(slab, qb.z, qb.w, qc.x, r2, limit, &n2);
-            const bool h3 = wide_box<OCT, ORDERED>(slab, qc.y, qc.z, qc.w, r3, limit, &n3);
+            const bool h0 = wide_box<OCT, ORDERED, BOUNDED>(slab, qa.x, qa.y, qa.z, r0, limit, bw, largeBit, &n0);
+            const bool h1 = wide_box<OCT, ORDERED, BOUNDED>(slab, qa.w, qb.x, qb.y, r1, limit, bw, largeBit, &n1);
+            const bool h2 = wide_box<OCT, ORDERED, BOUNDED>(slab, qb.z, qb.w, qc.x, r2, limit, bw, largeBit, &n2);
+            const bool h3 = wide_box<OCT, ORDERED, BOUNDED>(slab, qc.y, qc.z, qc.w, r3, limit, bw, largeBit, &n3);
             const bool l0 = (r0 & RT_LEAF_BIT) != 0, l1 = (r1 & RT_LEAF_BIT) != 0, l2 = (r2 & RT_LEAF_BIT) != 0, l3 = (r3 & RT_LEAF_BIT) != 0;
             // leaves whose box may pass: every store happens, the count moves on only where it is needed (the reference
             // goes in as it is, leaf bit and all: the triangle phase takes the bit off)
@@ -752,7 +766,59 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
             const float limit = h.t * sv.pruneScale;                 // +inf without a hit, or with the option off
             // front to back, with the boxes beyond `limit` left out, where that can end a walk sooner; as the boxes come otherwise
             const bool ordered = COUNT || Src::FIRST_HIT_MAY_DECIDE || sv.pruneScale < rt_inf();
-            if (sv.wnodes != nullptr && ordered) {
+            bool bounded = false;
+            // (camera, caller and bounce rays: where the 1.5 % rule is asked for it goes through the same phase, with the
+            //  support distance in place of the entry distance -- one ordered phase per kernel instead of two)
+            if constexpr (!Src::FIRST_HIT_MAY_DECIDE) bounded = sv.wnodes != nullptr && (sv.boundQ > 0.0f || sv.pruneScale < rt_inf() || COUNT);
+            if (bounded) {
+                if constexpr (!Src::FIRST_HIT_MAY_DECIDE) {
+                // ---- leaving out boxes, with a bound.  For a triangle the reference accepts (determinant >= 1e-8,
+                // u, v, u + v in range -- all as computed), the point o + t'd of the COMPUTED distance t' lies within
+                //     |r| <= 28.9 u |o - v0| |e1| |e2| |d| / determinant <= RT_BOUND_C |e1||e2| |o - v0| |d|      (u = 2^-24)
+                // of the point v0 + u'e1 + v'e2 of the triangle that the computed u', v' name: t', u', v' are Cramer
+                // quotients of three numerators and one determinant, each a dot product with a cross product (a cross
+                // product's components are off by 2u |a||b| each, 3.47u in norm, a three-term dot product by 3u |a||b|,
+                // o - v0 by u): each numerator is off by at most 7.47u |o - v0||e1||e2||d|, the determinant by 6.47u
+                // |e1||e2||d|, and M (t', u', v') - (o - v0) with M = [-d, e1, e2] collects exactly those errors over the
+                // determinant: 6.47 + 3 x 7.47 = 28.9.  The triangle's point is in
+                // every box that holds the triangle, so o + t'd is within |r| of the box: on each axis a, t' is at
+                // least (the ray's near value on a) - |r| / |d[a]|.  A triangle that could still change the answer has
+                // t' <= the closest hit t, so its v0 is within t|d| + |r| + (|e1| + |e2|) of o; with
+                // Q = RT_BOUND_C max|e1||e2| and E = max(|e1| + |e2|) over the scene's SMALL triangles and q = Q|d|
+                // that gives |r| <= |d| (q t + Q E) / (1 - q) =: |d| rho, and
+                //     max over a of (near value on a - rho |d| / |d[a]|) > t   =>   t' > t for every small triangle in
+                // the box: nothing in it can replace the hit or tie with it.  Boxes that hold a LARGE triangle carry a
+                // flag and are never left out.  (The near values are lower bounds that include their own roundings;
+                // rho is rounded up with room for the few operations that make it and for the second-order term
+                // 2 ulp (t + E / |d|) of the quotients' own roundings.)
+                // The 1.5 % rule (RT_OPT_PRUNE_BY_DISTANCE 2) goes through the same phase with rho = 0 and the room in
+                // the limit: near values as they are, large triangles or not.
+                float blimit = limit, b0 = 0.0f, b1 = 0.0f, b2 = 0.0f;
+                uint32_t largeBit = 0u;
+                if (sv.boundQ > 0.0f) {
+                    const float dl = rt_sqrt(rt_dot3(d, d));
+                    const float q = sv.boundQ * dl;
+                    const float rho = q < 0.5f ? ((q * h.t + sv.boundQ * sv.boundE) / (1.0f - q) + 9.5367431640625e-7f * (h.t + sv.boundE / dl)) * 1.0000153f : rt_inf();
+                    const float rd = rho * dl * 1.0000153f;
+                    b0 = rd * __builtin_fabsf(r.x) * 1.0000153f;
+                    b1 = rd * __builtin_fabsf(r.y) * 1.0000153f;
+                    b2 = rd * __builtin_fabsf(r.z) * 1.0000153f;
+                    blimit = h.t;
+                    largeBit = RT_REF_LARGE;
+                }
+                switch (oct) {
+                case 0: node_phase_wide<0, COUNT, true, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, blimit, shareTrips, b0, b1, b2, largeBit); break;
+                case 1: node_phase_wide<1, COUNT, true, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, blimit, shareTrips, b0, b1, b2, largeBit); break;
+                case 2: node_phase_wide<2, COUNT, true, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, blimit, shareTrips, b0, b1, b2, largeBit); break;
+                case 3: node_phase_wide<3, COUNT, true, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, blimit, shareTrips, b0, b1, b2, largeBit); break;
+                case 4: node_phase_wide<4, COUNT, true, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, blimit, shareTrips, b0, b1, b2, largeBit); break;
+                case 5: node_phase_wide<5, COUNT, true, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, blimit, shareTrips, b0, b1, b2, largeBit); break;
+                case 6: node_phase_wide<6, COUNT, true, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, blimit, shareTrips, b0, b1, b2, largeBit); break;
+                case 7: node_phase_wide<7, COUNT, true, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, blimit, shareTrips, b0, b1, b2, largeBit); break;
+                default: node_phase_wide<8, COUNT, true, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, blimit, shareTrips, b0, b1, b2, largeBit); break;
+                }
+                }
+            } else if (Src::FIRST_HIT_MAY_DECIDE && sv.wnodes != nullptr && ordered) {
                 switch (oct) {
                 case 0: node_phase_wide<0, COUNT, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
                 case 1: node_phase_wide<1, COUNT, true>(sv, slab, w, stk, pend, spill, spillLanes, cnt, feed.exhausted, limit, shareTrips); break;
@@ -807,7 +873,7 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
         if (COUNT) {
             for (uint32_t k = 0; __ballot(k < npend) != 0ull; ++k)
                 if (k < npend) {
-                    const bool boxed = tri_test<COUNT>(sv, pend[k * TRV_THREADS] & ~RT_LEAF_BIT, o, d, r, h);   // (the two-level walk queues references with their leaf bit)
+                    const bool boxed = tri_test<COUNT>(sv, pend[k * TRV_THREADS] & RT_REF_INDEX, o, d, r, h);   // (the two-level walk queues references as they are, flag bits and all)
                     cnt[1]++;
                     cnt[2] += boxed ? 1u : 0u;
                 }
@@ -830,8 +896,8 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                 pN[4] += (unsigned long long)nLeft;
 #endif
                 const bool t0 = k < npend, t1 = k + 1u < npend;
-                const uint32_t leaf0 = t0 ? pend[k * TRV_THREADS] & ~RT_LEAF_BIT : 0u;
-                const uint32_t leaf1 = t1 ? pend[(k + 1u) * TRV_THREADS] & ~RT_LEAF_BIT : 0u;
+                const uint32_t leaf0 = t0 ? pend[k * TRV_THREADS] & RT_REF_INDEX : 0u;
+                const uint32_t leaf1 = t1 ? pend[(k + 1u) * TRV_THREADS] & RT_REF_INDEX : 0u;
                 const float4 *p0 = (const float4 *)(sv.leafTri + leaf0), *p1 = (const float4 *)(sv.leafTri + leaf1);
                 const float4 a0 = p0[0], b0 = p0[1], c0 = p0[2];
                 const float4 a1 = p1[0], b1 = p1[1], c1 = p1[2];

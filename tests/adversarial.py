@@ -24,18 +24,22 @@ def _unit(v):
     return v / np.linalg.norm(v, axis=-1, keepdims=True)
 
 
-def grazing_cells(n_cells=2048, fans=3, seed=41):
-    """-> (Scene, cells) with cells = dict of per-cell float64 arrays (origin, direction, a, b, theta, t_h)."""
+def grazing_cells(n_cells=2048, fans=3, seed=41, scale=1.0, theta_decades=(-7.0, -4.0), behind=(0.017, 0.3)):
+    """-> (Scene, cells) with cells = dict of per-cell float64 arrays (origin, direction, a, b, theta, t_h).
+    scale: every length of the scene times this (the reference's cut, determinant < 1e-8, is absolute: in a scene 256
+    times smaller a ray has to meet a plane at 1e-4 rad or more for the triangle to survive it, and what Moller-Trumbore
+    can be off by is bounded -- the scene for the rule that leaves boxes out with a bound); theta_decades: the grazing
+    angles, as powers of ten; behind: how far behind H the fans start, as fractions of H's distance."""
     rs = np.random.Generator(np.random.PCG64(seed))
     side = int(np.ceil(n_cells ** (1 / 3)))
     grid = np.stack(np.meshgrid(*[np.arange(side)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n_cells]
-    origin = (grid - (side - 1) / 2) * (180.0 / side) + rs.uniform(-1, 1, (n_cells, 3))
+    origin = ((grid - (side - 1) / 2) * (180.0 / side) + rs.uniform(-1, 1, (n_cells, 3))) * scale
     d = _unit(rs.normal(size=(n_cells, 3)))
     helper = np.where(np.abs(d[:, :1]) > 0.9, np.array([[0, 1.0, 0]]), np.array([[1.0, 0, 0]]))
     a = _unit(np.cross(d, helper))
     b = np.cross(d, a)
-    t_h = rs.uniform(0.5, 5.0, n_cells)
-    theta = 10.0 ** rs.uniform(-7, -4, n_cells)
+    t_h = rs.uniform(0.5, 5.0, n_cells) * scale
+    theta = 10.0 ** rs.uniform(theta_decades[0], theta_decades[1], n_cells)
     tris = []
     # H: an equilateral triangle of circumradius 0.05 t_h square to d, facing the origin (e1 x e2 against d)
     r = 0.05 * t_h[:, None]
@@ -47,16 +51,16 @@ def grazing_cells(n_cells=2048, fans=3, seed=41):
     for f in range(fans):
         th = theta * (0.5, 1.0, 2.0)[f % 3]
         g = np.cos(th)[:, None] * d + np.sin(th)[:, None] * b                # in-plane direction, nearly the ray's
-        behind = t_h * (1.0 + 10.0 ** rs.uniform(np.log10(0.017), np.log10(0.3), n_cells))   # where the cell's central ray crosses the plane: 1.7 % .. 30 % behind H
-        p = origin + d * behind[:, None]
-        L1 = rs.uniform(1.0, 3.0, n_cells)[:, None]
-        L2 = rs.uniform(0.3, 2.0, n_cells)[:, None]
+        behind_h = t_h * (1.0 + 10.0 ** rs.uniform(np.log10(behind[0]), np.log10(behind[1]), n_cells))   # where the cell's central ray crosses the plane: 1.7 % .. 30 % behind H
+        p = origin + d * behind_h[:, None]
+        L1 = rs.uniform(1.0, 3.0, n_cells)[:, None] * scale
+        L2 = rs.uniform(0.3, 2.0, n_cells)[:, None] * scale
         sliver = rs.random(n_cells) < 0.5
         phi = np.where(sliver, 10.0 ** rs.uniform(-3, -1, n_cells), np.pi / 2)[:, None]
         side_sign = np.where(rs.random(n_cells) < 0.5, 1.0, -1.0)[:, None]
         e1 = L1 * g
         e2 = L2 * (np.cos(phi) * g + np.sin(phi) * side_sign * a)
-        v0 = p - 1e-3 * behind[:, None] * (g + side_sign * a)                 # the crossing point sits just inside the corner
+        v0 = p - 1e-3 * behind_h[:, None] * (g + side_sign * a)                 # the crossing point sits just inside the corner
         # front face towards the origin: d . (e1 x e2) < 0
         flip = np.einsum("ij,ij->i", d, np.cross(e1, e2)) > 0
         e1f = np.where(flip[:, None], e2, e1)
@@ -71,7 +75,7 @@ def grazing_cells(n_cells=2048, fans=3, seed=41):
     mats = np.array([scenes.material_data((0.7, 0.7, 0.7, 1), 0, 0.3)], wire.MATERIAL)
     sc = scenes.Scene("grazing cells", v, np.arange(len(pos), dtype=np.uint32), np.zeros(n_tri, np.uint32), np.ones((n_tri, 2), np.int32), mats,
                       notes="adversarial: slivers and large triangles met at 1e-7 .. 1e-4 rad behind a well-shaped hit")
-    sc.params = scenes.make_params(32, 32, (0, 0, -260), fov=50.0, sampling=wire.SAMPLING_COSINE)
+    sc.params = scenes.make_params(32, 32, (0, 0, -260 * scale), fov=50.0, sampling=wire.SAMPLING_COSINE)
     return sc, dict(origin=origin, direction=d, a=a, b=b, theta=theta, t_h=t_h)
 
 

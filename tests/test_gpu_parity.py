@@ -101,8 +101,9 @@ def test_first_hit_bit_exact(core, oracle, name, packets):
     o = np.concatenate([o1, o2, o3])
     d = np.concatenate([d1, d2, d3])
     core.set_option(wire.OPT_PACKET_TRACE, packets)
-    # Caller rays enter every box they pass (RT_OPT_PRUNE_BY_DISTANCE 0 and the default 1 alike): the walk whose work
-    # the checker counts.  2 leaves boxes beyond the closest hit out for these rays as well.
+    # With RT_OPT_PRUNE_BY_DISTANCE 0 caller rays enter every box they pass: the walk whose work the checker counts.
+    # The default (1) leaves boxes out by the bounded rule -- same hits, less work --, 2 by the 1.5 % rule.
+    core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 0)
     core.enable_counters(True)
     core.reset_stats()
     got = core.trace_rays(o, d)
@@ -122,14 +123,22 @@ def test_first_hit_bit_exact(core, oracle, name, packets):
     got_every_box = core.trace_rays(o, d)
     core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 1)
     got_plain = core.trace_rays(o, d)
+    core.enable_counters(True)
+    core.reset_stats()
+    got_counting_default = core.trace_rays(o, d)
+    st_default = core.stats()
+    core.enable_counters(False)
     core.set_option(wire.OPT_PACKET_TRACE, False)
     for k in ("triangle", "t", "u", "v"):
         H.assert_bits_equal(got_plain[k], got[k], f"{k}: counting vs plain kernel")
         H.assert_bits_equal(got_narrow[k], got[k], f"{k}: two levels of the tree per step vs one")
-        H.assert_bits_equal(got_every_box[k], got[k], f"{k}: option 0 vs the default")
+        H.assert_bits_equal(got_every_box[k], got[k], f"{k}: option 0, plain kernel vs counting kernel")
+        H.assert_bits_equal(got_counting_default[k], got[k], f"{k}: counting kernel with the default vs option 0")
         H.assert_bits_equal(got_fewer[k], got[k], f"{k}: boxes beyond the closest hit left out")
         H.assert_bits_equal(got_counting_fewer[k], got[k], f"{k}: counting kernel, boxes beyond the closest hit left out")
     assert st_fewer["rays"] == st["rays"] and st_fewer["hits"] == st["hits"]
+    assert st_default["rays"] == st["rays"] and st_default["hits"] == st["hits"]
+    assert st_default["internalVisits"] <= st["internalVisits"] and st_default["triTests"] <= st["triTests"]
     assert st_fewer["internalVisits"] <= st["internalVisits"] and st_fewer["triTests"] <= st["triTests"]
     if not packets and name in ("cornell", "soup20k"):
         assert st_fewer["internalVisits"] < st["internalVisits"]
@@ -180,15 +189,23 @@ def test_first_hit_bit_exact_on_the_full_car(core, oracle):
     o = np.concatenate([o1, o2, a])
     d = np.concatenate([d1, d2, d3.astype(np.float32)])
     want = orc.trace(o, d)
+    core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 0)       # every box a ray passes: the walk the checker counts
     core.enable_counters(True)
     core.reset_stats()
     got = core.trace_rays(o, d)
     st = core.stats()
+    core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 1)       # the default: boxes left out by the bounded rule
+    core.reset_stats()
+    got_default = core.trace_rays(o, d)
+    st_default = core.stats()
     core.enable_counters(False)
     plain = core.trace_rays(o, d)
     for k in ("triangle", "t", "u", "v"):
         H.assert_bits_equal(got[k], want[k], f"{k}: counting kernel vs the reference's walk")
+        H.assert_bits_equal(got_default[k], want[k], f"{k}: counting kernel, bounded rule vs the reference's walk")
         H.assert_bits_equal(plain[k], want[k], f"{k}: plain kernel vs the reference's walk")
+    # the car's triangles are small ones (the ground's two are not): the rule has to leave a good part of the boxes out
+    assert st_default["internalVisits"] < 0.8 * st["internalVisits"], (st_default, st)
     want_counters = orc.trace(o, d, wide=True)["counters"]
     for k in ("rays", "internalVisits", "leafVisits", "triTests", "hits"):
         assert st[k] == want_counters[k], f"counter {k}: gpu {st[k]} vs checker {want_counters[k]}"
@@ -399,7 +416,7 @@ def test_long_walks_shared_between_lanes_do_not_change_a_bit(core, oracle):
                 c.bvh_build()
                 for o, d in rays:
                     want = orc.trace(o, d)
-                    for prune, wide in ((2, 0), (0, 0), (2, 1), (1, 1)):   # (caller rays enter every box with 0 and with the default 1)
+                    for prune, wide in ((2, 0), (0, 0), (2, 1), (1, 1), (0, 1)):   # (0 with the two-level walk: the step that sorts nothing)
                         c.set_option(wire.OPT_PRUNE_BY_DISTANCE, prune)
                         c.set_option(wire.OPT_WIDE_NODES, wide)
                         for on in (1, 0):
