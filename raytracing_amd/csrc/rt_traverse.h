@@ -780,7 +780,9 @@ __device__ __forceinline__ void traverse_rays(const RtSceneView &sv, Src &src, u
                 // product's components are off by 2u |a||b| each, 3.47u in norm, a three-term dot product by 3u |a||b|,
                 // o - v0 by u): each numerator is off by at most 7.47u |o - v0||e1||e2||d|, the determinant by 6.47u
                 // |e1||e2||d|, and M (t', u', v') - (o - v0) with M = [-d, e1, e2] collects exactly those errors over the
-                // determinant: 6.47 + 3 x 7.47 = 28.9.  The triangle's point is in
+                // determinant: 6.47 + 3 x 7.47 = 28.9.  (u' >= 0, v' >= 0 and fl(u' + v') <= 1 put that point in the
+                // triangle up to a rounding of u' + v' and of the stored edges -- parts in 10^8 of an edge, which the
+                // 0.001 by which every triangle's box is padded absorbs.)  The triangle's point is in
                 // every box that holds the triangle, so o + t'd is within |r| of the box: on each axis a, t' is at
                 // least (the ray's near value on a) - |r| / |d[a]|.  A triangle that could still change the answer has
                 // t' <= the closest hit t, so its v0 is within t|d| + |r| + (|e1| + |e2|) of o; with

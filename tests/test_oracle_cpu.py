@@ -529,7 +529,7 @@ def test_grid_walk_keeps_the_reference_winner_among_coincident_triangles(oracle)
 
 
 def test_leaving_out_boxes_beyond_the_closest_hit_is_not_exact(oracle):
-    """Why camera rays and caller rays enter every box by default (RT_OPT_PRUNE_BY_DISTANCE): on rays that run nearly
+    """Why no ray leaves out a box on the strength of distances alone by default (RT_OPT_PRUNE_BY_DISTANCE 2 does): on rays that run nearly
     inside the planes of large triangles and slivers (tests/adversarial.py) Moller-Trumbore puts some of those
     triangles in front of the well-shaped triangle before them, the reference's walk -- which tests every triangle
     whose box the ray passes -- returns them, and a walk that skips boxes beginning 1/64 or 1/16 beyond the hit it
