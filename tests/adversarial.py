@@ -93,3 +93,33 @@ def grazing_rays(cells, rays_per_cell, seed=43):
     d = _unit(d)
     o = cells["origin"][:, None, :] + zeta[..., None] * cells["b"][:, None, :]
     return o.reshape(-1, 3).astype(F32), d.reshape(-1, 3).astype(F32)
+
+
+def rays_in_the_planes_of(scene, n, seed=53, angle_decades=(-6.0, -1.5), start=(0.05, 6.0)):
+    """n rays that run nearly inside the planes of triangles of `scene` itself: for a random triangle, a point in it, an
+    in-plane direction turned out of the plane by +-10^angle_decades rad, and an origin `start` units back along that
+    direction -- so the ray meets the triangle at a grazing angle with whatever else the scene holds in front of it and
+    behind it.  The rays a rule that leaves boxes out has to survive on a scene of ordinary shapes."""
+    rs = np.random.Generator(np.random.PCG64(seed))
+    v = np.asarray(scene.vertices["position"], np.float64)
+    idx = np.asarray(scene.indices, np.int64).reshape(-1, 3)
+    t = rs.integers(0, len(idx), n)
+    p0, p1, p2 = v[idx[t, 0]], v[idx[t, 1]], v[idx[t, 2]]
+    e1, e2 = p1 - p0, p2 - p0
+    nrm = np.cross(e1, e2)
+    ok = np.linalg.norm(nrm, axis=1) > 0
+    nrm[~ok] = (0, 1, 0)
+    nrm = _unit(nrm)
+    a, b = rs.random(n), rs.random(n)
+    flip = a + b > 1
+    a[flip], b[flip] = 1 - a[flip], 1 - b[flip]
+    point = p0 + a[:, None] * e1 + b[:, None] * e2
+    phi = rs.uniform(0, 2 * np.pi, n)
+    x = _unit(np.where(np.linalg.norm(e1, axis=1, keepdims=True) > 0, e1, np.array([[1.0, 0, 0]])))
+    y = np.cross(nrm, x)
+    inplane = np.cos(phi)[:, None] * x + np.sin(phi)[:, None] * y
+    theta = 10.0 ** rs.uniform(angle_decades[0], angle_decades[1], n) * rs.choice([-1.0, 1.0], n)
+    d = _unit(np.cos(theta)[:, None] * inplane - np.sin(theta)[:, None] * nrm)      # (-normal: towards the front face for theta > 0)
+    back = rs.uniform(start[0], start[1], n)
+    o = point - d * back[:, None]
+    return o.astype(F32), d.astype(F32)

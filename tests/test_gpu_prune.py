@@ -90,6 +90,28 @@ def test_grazing_rays_in_a_scene_of_small_triangles_with_the_bounded_rule_at_wor
     assert work[1]["rays"] == work[0]["rays"] and work[1]["hits"] == work[0]["hits"]
 
 
+def test_rays_in_the_planes_of_the_cars_own_triangles(core, oracle):
+    """The bench scene at full detail, and two million rays that run within 1e-6 .. 3e-2 rad of the planes of its own
+    (small) triangles, started 0.05 .. 6 units back: the bounded rule at work on the geometry it was made for."""
+    from raytracing_amd import scenes
+    sc = scenes.car_standin(64, 64, detail=1.0)
+    o, d = adversarial.rays_in_the_planes_of(sc, 2_000_000)
+    orc = oracle.Oracle(sc).build()
+    want = orc.trace(o, d)
+    core.upload(sc)
+    core.bvh_build()
+    hit = want["triangle"] != 0xFFFFFFFF
+    assert hit.mean() > 0.5
+    for value in (1, 0):
+        core.set_option(wire.OPT_PRUNE_BY_DISTANCE, value)
+        got = core.trace_rays(o, d)
+        H.assert_bits_equal(got["triangle"], want["triangle"], f"first-hit triangle, option {value}")
+        H.assert_bits_equal(got["t"], want["t"], f"hit distance, option {value}")
+        H.assert_bits_equal(got["u"][hit], want["u"][hit], f"u, option {value}")
+        H.assert_bits_equal(got["v"][hit], want["v"][hit], f"v, option {value}")
+    core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 1)
+
+
 def test_frames_with_bounce_rays_pruned_are_the_checkers(core, oracle):
     """Whole frames -- camera, bounce and soft-shadow rays -- on a scene of ordinary shapes: the frame is the checker's
     bit for bit with the bounded rule (1, the default), with no box left out (0) and with the 1.5 % rule (2)."""

@@ -557,3 +557,63 @@ def test_leaving_out_boxes_beyond_the_closest_hit_is_not_exact(oracle):
         assert (got["t"][moved] >= ref["t"][moved]).all()
     assert changed[1.015625] >= 10 and changed[1.0625] >= 3, changed
     assert changed[1.0625] <= changed[1.015625]
+
+
+def test_the_bound_behind_leaving_boxes_out_holds_on_grazing_rays():
+    """RT_OPT_PRUNE_BY_DISTANCE 1 rests on one inequality: for a triangle IntersectTriangle_MT97 accepts (determinant
+    >= 1e-8, u, v, u + v in range, all as computed in float32), the point o + t'd lies within
+    28.9 * 2^-24 |o - v0||e1||e2||d| / det + 2 * 2^-24 (t'|d| + |e1| + |e2|) of the point v0 + u'e1 + v'e2.
+    The reference's arithmetic is redone here in float32 (same operations, same association as rt_math.h) on two
+    million rays aimed at small triangles and slivers at 1e-7 .. 0.1 rad (800 000 of them accepted), the residual is taken in float64, and the
+    worst ratio to the bound is printed: the analysis is a worst case, the rays stay well inside it."""
+    f = np.float32
+    rs = np.random.Generator(np.random.PCG64(5))
+
+    def cross(a, b):
+        return np.stack([a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1], a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2], a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]], 1)
+
+    def dot(a, b):
+        return (a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1]) + a[:, 2] * b[:, 2]
+
+    worst, accepted = 0.0, 0
+    for _ in range(8):
+        n = 250_000
+        v0 = rs.uniform(-3, 3, (n, 3))
+        g = rs.normal(size=(n, 3)); g /= np.linalg.norm(g, axis=1, keepdims=True)
+        h = rs.normal(size=(n, 3)); h -= (h * g).sum(1, keepdims=True) * g; h /= np.linalg.norm(h, axis=1, keepdims=True)
+        phi = np.where(rs.random(n) < 0.5, 10 ** rs.uniform(-3, 0, n), np.pi / 2)           # half of them slivers
+        e1 = (10 ** rs.uniform(-3, -0.7, n))[:, None] * g
+        e2 = (10 ** rs.uniform(-3, -0.7, n))[:, None] * (np.cos(phi)[:, None] * g + np.sin(phi)[:, None] * h)
+        nrm = np.cross(e1, e2); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        a, b = rs.random(n), rs.random(n)
+        fl = a + b > 1; a[fl] = 1 - a[fl]; b[fl] = 1 - b[fl]
+        point = v0 + a[:, None] * e1 + b[:, None] * e2
+        ang = rs.uniform(0, 2 * np.pi, n)
+        inplane = np.cos(ang)[:, None] * g + np.sin(ang)[:, None] * np.cross(nrm, g)
+        th = 10 ** rs.uniform(-7, -1, n)
+        d = np.cos(th)[:, None] * inplane - np.sin(th)[:, None] * nrm
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        o = point - d * (10 ** rs.uniform(-2, 1, n))[:, None]
+        o32, d32, v032 = o.astype(f), d.astype(f), v0.astype(f)
+        e132, e232 = (v0 + e1).astype(f) - v032, (v0 + e2).astype(f) - v032
+        with np.errstate(all="ignore"):
+            pvec = cross(d32, e232)
+            det = dot(e132, pvec)
+            inv = f(1) / det
+            tvec = o32 - v032
+            u = dot(tvec, pvec) * inv
+            qvec = cross(tvec, e132)
+            v = dot(d32, qvec) * inv
+            t = dot(e232, qvec) * inv
+            acc = (det >= f(1e-8)) & (u >= 0) & (u <= 1) & (v >= 0) & ((u + v) <= 1) & (t > 0)
+        assert pvec.dtype == f and t.dtype == f
+        accepted += int(acc.sum())
+        O, D, V0, E1, E2 = [x.astype(np.float64)[acc] for x in (o32, d32, v032, e132, e232)]
+        T, U, V, DET = [x.astype(np.float64)[acc] for x in (t, u, v, det)]
+        r = np.linalg.norm(O + T[:, None] * D - (V0 + U[:, None] * E1 + V[:, None] * E2), axis=1)
+        tv, l1, l2, dl = [np.linalg.norm(x, axis=1) for x in (O - V0, E1, E2, D)]
+        bound = 28.9 * 2.0 ** -24 * tv * l1 * l2 * dl / DET + 2 * 2.0 ** -24 * (T * dl + l1 + l2)
+        worst = max(worst, float((r / bound).max()))
+    print(f"\n{accepted} accepted grazing hits: largest residual / bound = {worst:.3f}")
+    assert accepted > 500_000
+    assert worst < 1.0
