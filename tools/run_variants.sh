@@ -1,3 +1,7 @@
+#!/bin/bash
+# A/B of library variants built with tools/build_variant.sh: for each name, the end-of-launch numbers (0.26 M and 2.07 M camera
+# rays, tools/exp_share.py), the bench step and drop-in sequence, and an eighth of the image (tools/rank_share.py).
+# Usage (GPU box, repository root): tools/run_variants.sh <name> [<name> ...]      (build_ab/librtcore_<name>.so)
 for n in "$@"; do
   echo "== $n"
   export RTCORE_LIB=build_ab/librtcore_$n.so
