@@ -383,8 +383,8 @@ def main():
 
     # ---- the per-frame drop-in sequence (untimed by `value`): what RayTracing.CustomRender does once per
     # OnRenderImage (RayTracing.cs:118-164) when the host keeps its own frame loop: UpdateParameters (new seed),
-    # Dispatch(CSMain), Dispatch(ShadowMap), Blit(addMaterial) -- one frame in flight, nothing shared between passes.
-    dropin_frames = 0 if args.no_dropin else min(args.spp, 16)
+    # Dispatch(CSMain), Dispatch(ShadowMap), Blit(addMaterial) -- the host makes the calls one frame at a time.
+    dropin_frames = 0 if args.no_dropin else min(args.spp, 32)
     dropin_ms = None
     dropin_readback_ms = {}
     if dropin_frames:
@@ -516,7 +516,7 @@ def main():
                 "ms_per_frame_1spp": round(dropin_ms, 4), "frames": dropin_frames,
                 "ms_per_frame_with_a_full_frame_readback": dropin_readback_ms,
                 "sequence": "rt_set_params(seed) + rt_dispatch + rt_dispatch_shadowmap + rt_accumulate per frame (RayTracing.cs:118-164); "
-                            "the library keeps two such frames in flight (RT_OPT_PIPELINE_FRAMES)"},
+                            "the library keeps four such frames in flight (RT_OPT_PIPELINE_FRAMES)"},
             "paths_per_step": args.width * args.height * args.spp,
             "bvh_build_ms": round(build_ms, 3),
             "bvh_build_first_ms": round(build_first_ms, 3),

@@ -486,14 +486,16 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *                          work (rt_enable_counters) walk the same way as the others: internalVisits counts the places of
  *                          the records fetched that hold a child (two per node visited with one level per step).
  *   RT_OPT_PIPELINE_FRAMES 1 (default): the per-frame call sequence -- rt_set_params (new seed), rt_dispatch, rt_dispatch_shadowmap,
- *                          rt_accumulate per frame, as RayTracing.CustomRender makes it (RayTracing.cs:118-164) -- keeps TWO
- *                          frames in flight: consecutive frames go down two lanes (stream, frame of path state, counter
+ *                          rt_accumulate per frame, as RayTracing.CustomRender makes it (RayTracing.cs:118-164) -- keeps FOUR
+ *                          frames in flight: consecutive frames go round four lanes (stream, frame of path state, counter
  *                          block, masked streams, spill areas of their own), so the launches of a frame fill the idle time
- *                          of the frame before, most of whose launches are as long as their longest ray.  The folds into
- *                          the running mean stay in frame order (each waits for the one before), so the images keep their
- *                          bits; RT_IMAGE_RT / RT_IMAGE_SHADOWMAP show the frame of the last rt_dispatch.  Any call other
- *                          than those four (and rt_set_dirty) first lets both lanes run out.  Off while counters or kernel
- *                          timing are enabled, with RT_OPT_TWO_STREAMS and with the brute-force flag.
+ *                          of the frames before, most of whose launches are as long as their longest ray (one frame at a
+ *                          time 4.2 ms, two lanes 3.0, three 2.6, four 2.4; six and eight lanes are slower again).  The folds
+ *                          into the running mean stay in frame order (each waits for the one before), so the images keep
+ *                          their bits; RT_IMAGE_RT / RT_IMAGE_SHADOWMAP show the frame of the last rt_dispatch.  Any call
+ *                          other than those four (and rt_set_dirty) first lets all lanes run out.  2, 3, 4: that many
+ *                          lanes; 0: one frame at a time.  Off while counters or kernel timing are enabled, with
+ *                          RT_OPT_TWO_STREAMS and with the brute-force flag.
  *   RT_OPT_OVERLAP_AFTER   0..6, default 0: the bounce whose extend launch the overlap starts after (0: as soon as the
  *                          primary hits are known)
  *   RT_OPT_OVERLAP_CUS     compute units the bounce launches keep meanwhile, default 64 (multiples of 32 measured best);

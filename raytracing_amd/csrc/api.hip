@@ -119,6 +119,21 @@ static int check_error_flag(RtContext *ctx)
     return RT_OK;
 }
 
+// streams and events of the frame lanes 1 .. RT_FRAME_LANES - 1 (lane 1's stream is stream2, made by the caller)
+static bool rt_create_lanes(RtContext *ctx)
+{
+    ctx->laneStream[1] = ctx->stream2;
+    for (int k = 0; k < RT_FRAME_LANES; ++k) {
+        if (k >= 2 && hipStreamCreateWithFlags(&ctx->laneStream[k], hipStreamNonBlocking) != hipSuccess) return false;
+        if (k >= 1 && (hipEventCreateWithFlags(&ctx->laneFork[k], hipEventDisableTiming) != hipSuccess ||
+                       hipEventCreateWithFlags(&ctx->laneJoin[k], hipEventDisableTiming) != hipSuccess ||
+                       hipEventCreateWithFlags(&ctx->evLaneIdle[k], hipEventDisableTiming) != hipSuccess))
+            return false;
+        if (hipEventCreateWithFlags(&ctx->evAccumulated[k], hipEventDisableTiming) != hipSuccess) return false;
+    }
+    return true;
+}
+
 extern "C" {
 
 const char *rt_version(void) { return "rtcore 0.1 (gfx950)"; }
@@ -143,11 +158,7 @@ int rt_create(int device_id, RtContext **out_ctx)
         hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->evFork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->evJoin, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->evFork1, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->evJoin1, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->evAccumulated[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->evAccumulated[1], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->evLane1Idle, hipEventDisableTiming) != hipSuccess ||
+        !rt_create_lanes(ctx) ||
         hipMalloc((void **)&ctx->dStats, 64 * sizeof(unsigned long long)) != hipSuccess ||
         hipMalloc((void **)&ctx->dNonCasters, RT_NONCASTER_LIST * 64) != hipSuccess ||
         hipMalloc((void **)&ctx->dErrorFlag, 4) != hipSuccess || hipMalloc((void **)&ctx->dQCount, RT_COUNTER_BLOCK_WORDS * 4) != hipSuccess ||
@@ -177,9 +188,13 @@ int rt_destroy(RtContext *ctx)
         (void)rt_join_lanes(ctx);
         (void)hipStreamSynchronize(ctx->stream);
     }
-    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
-    for (hipStream_t st : {ctx->streamShadow, ctx->streamChain, ctx->streamShadow1, ctx->streamChain1})
+    for (int k = 1; k < RT_FRAME_LANES; ++k)
+        if (ctx->laneStream[k]) (void)hipStreamSynchronize(ctx->laneStream[k]);
+    for (hipStream_t st : {ctx->streamShadow, ctx->streamChain})
         if (st) (void)hipStreamSynchronize(st);
+    for (int k = 1; k < RT_FRAME_LANES; ++k)
+        for (hipStream_t st : {ctx->laneShadow[k], ctx->laneChain[k]})
+            if (st) (void)hipStreamSynchronize(st);
     rt_timer_resolve(ctx);
     for (hipEvent_t e : ctx->eventPool) (void)hipEventDestroy(e);
     rt_free_build(ctx);
@@ -194,13 +209,18 @@ int rt_destroy(RtContext *ctx)
         (void)hipStreamSynchronize(ctx->streamCopy);
         (void)hipStreamDestroy(ctx->streamCopy);
         (void)hipEventDestroy(ctx->evExpanded);
-        (void)hipEventDestroy(ctx->evCopied);
+        (void)hipEventDestroy(ctx->evCopied[0]);
+        (void)hipEventDestroy(ctx->evCopied[1]);
     }
     if (ctx->dReadbackFull) (void)hipFree(ctx->dReadbackFull);
-    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2), (void)hipStreamDestroy(ctx->stream2);
+    for (int k = 1; k < RT_FRAME_LANES; ++k)
+        if (ctx->laneStream[k]) (void)hipStreamSynchronize(ctx->laneStream[k]), (void)hipStreamDestroy(ctx->laneStream[k]);
     rt_release_overlap_streams(ctx);
-    for (hipEvent_t e : {ctx->evFork, ctx->evJoin, ctx->evFork1, ctx->evJoin1, ctx->evAccumulated[0], ctx->evAccumulated[1], ctx->evLane1Idle})
+    for (hipEvent_t e : {ctx->evFork, ctx->evJoin})
         if (e) (void)hipEventDestroy(e);
+    for (int k = 0; k < RT_FRAME_LANES; ++k)
+        for (hipEvent_t e : {ctx->laneFork[k], ctx->laneJoin[k], ctx->evAccumulated[k], ctx->evLaneIdle[k]})
+            if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RT_OK;
@@ -527,15 +547,18 @@ int rt_readback_async(RtContext *ctx, int which, float *pinned_dst_rgba)
     if (!ctx->streamCopy) {
         RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->streamCopy, hipStreamNonBlocking));
         RT_HIP(ctx, hipEventCreateWithFlags(&ctx->evExpanded, hipEventDisableTiming));
-        RT_HIP(ctx, hipEventCreateWithFlags(&ctx->evCopied, hipEventDisableTiming));
+        RT_HIP(ctx, hipEventCreateWithFlags(&ctx->evCopied[0], hipEventDisableTiming));
+        RT_HIP(ctx, hipEventCreateWithFlags(&ctx->evCopied[1], hipEventDisableTiming));
     }
     if (ctx->readbackPixels != px) {
-        if (ctx->copyPending) RT_HIP(ctx, hipEventSynchronize(ctx->evCopied));
-        ctx->copyPending = false;
+        for (int k = 0; k < 2; ++k) {
+            if (ctx->copyPending[k]) RT_HIP(ctx, hipEventSynchronize(ctx->evCopied[k]));
+            ctx->copyPending[k] = false;
+        }
         if (ctx->dReadbackFull) (void)hipFree(ctx->dReadbackFull);
         ctx->dReadbackFull = nullptr;
         ctx->readbackPixels = 0;
-        RT_HIP(ctx, hipMalloc((void **)&ctx->dReadbackFull, (px ? px : 1) * sizeof(float4)));
+        RT_HIP(ctx, hipMalloc((void **)&ctx->dReadbackFull, 2 * (px ? px : 1) * sizeof(float4)));
         ctx->readbackPixels = px;
     }
     return rt_readback_async_impl(ctx, src, pinned_dst_rgba);
@@ -544,10 +567,14 @@ int rt_readback_async(RtContext *ctx, int which, float *pinned_dst_rgba)
 int rt_readback_wait(RtContext *ctx)
 {
     RT_ENTER_FRAME(ctx);
-    if (!ctx->copyPending) return RT_OK;
-    RT_HIP(ctx, hipEventSynchronize(ctx->evCopied));
-    ctx->copyPending = false;
-    return check_error_flag(ctx);
+    bool any = false;
+    for (int k = 0; k < 2; ++k) {
+        if (!ctx->copyPending[k]) continue;
+        RT_HIP(ctx, hipEventSynchronize(ctx->evCopied[k]));
+        ctx->copyPending[k] = false;
+        any = true;
+    }
+    return any ? check_error_flag(ctx) : RT_OK;
 }
 
 /* This context's tiles into a full frame that already lives in device memory, on this context's device or on another
@@ -739,7 +766,10 @@ int rt_set_option(RtContext *ctx, int option, int value)
         return RT_OK;
     case RT_OPT_SHARE_LONG_WALKS: ctx->optShareLongWalks = value != 0; return RT_OK;
     case RT_OPT_WIDE_NODES: ctx->optWideNodes = value != 0; return RT_OK;
-    case RT_OPT_PIPELINE_FRAMES: ctx->optPipelineFrames = value != 0; return RT_OK;
+    case RT_OPT_PIPELINE_FRAMES:
+        if (value < 0 || value > RT_FRAME_LANES) return rt_fail(ctx, RT_E_INVALID, "RT_OPT_PIPELINE_FRAMES must be 0 .. %d", RT_FRAME_LANES);
+        ctx->optPipelineFrames = value == 0 ? 1 : (value == 1 ? RT_FRAME_LANES : value);
+        return RT_OK;
     case RT_OPT_PACKET_SHADOW: ctx->optPacketShadow = value != 0; return RT_OK;
     case RT_OPT_PACKET_PRIMARY: ctx->optPacketPrimary = value != 0; return RT_OK;
     case RT_OPT_PACKET_TRACE: ctx->optPacketTrace = value != 0; return RT_OK;

@@ -748,7 +748,7 @@ RtSceneView rt_scene_view(RtContext *ctx)
 #define CNT_FETCH_SM1 (21 * CNT_LINE)
 #define CNT_FETCH_TRACE (22 * CNT_LINE)
 #define CNT_WORDS (24 * CNT_LINE)
-static_assert(2 * CNT_WORDS <= RT_COUNTER_BLOCK_WORDS, "counter block too small");   // one per stream
+static_assert(RT_FRAME_LANES * CNT_WORDS <= RT_COUNTER_BLOCK_WORDS, "counter block too small");   // one per lane
 #define RT_MAX_BATCH 64u
 #define RT_BATCH_PATH_SLOTS (1u << 27)   // frames in flight are chosen so that a launch covers up to this many paths (220 B each: 29 GB)
 
@@ -815,7 +815,7 @@ int rt_alloc_render(RtContext *ctx)
     RT_HIP(ctx, hipMemsetAsync(ctx->dConv, 0, m * sizeof(float4), ctx->stream));
     ctx->allocSlots = n;
     ctx->sampleCount = 0;
-    return alloc_batch(ctx, 2);     // a frame of path state for each lane of the per-frame call sequence
+    return alloc_batch(ctx, RT_FRAME_LANES);     // a frame of path state for each lane of the per-frame call sequence
 }
 
 // Frames rt_render_frames keeps in flight for a tile share of nSlots path slots: `option` = RT_OPT_BATCH_FRAMES
@@ -981,7 +981,7 @@ static uint32_t walker_blocks_per_cu()
 // when the last of those contexts is destroyed; the split is the one the first of them asked for.
 struct RtMaskedStreams {
     uint32_t few = 0, users = 0;
-    hipStream_t shadow[2] = {nullptr, nullptr}, chain[2] = {nullptr, nullptr};   // a pair per frame lane, same masks
+    hipStream_t shadow[RT_FRAME_LANES] = {}, chain[RT_FRAME_LANES] = {};   // a pair per frame lane, same masks
 };
 static std::mutex g_maskedMutex;
 static std::map<int, RtMaskedStreams> g_masked;
@@ -1000,12 +1000,12 @@ static bool overlap_streams_ready(RtContext *ctx)
         std::vector<uint32_t> most(words, 0u), rest(words, 0u);
         for (uint32_t cu = 0; cu < n; ++cu) (cu < n - few ? most : rest)[cu >> 5] |= 1u << (cu & 31u);
         bool ok = true;
-        for (int lane = 0; lane < 2 && ok; ++lane)
+        for (int lane = 0; lane < RT_FRAME_LANES && ok; ++lane)
             ok = hipExtStreamCreateWithCUMask(&m.shadow[lane], words, most.data()) == hipSuccess &&
                  hipExtStreamCreateWithCUMask(&m.chain[lane], words, rest.data()) == hipSuccess;
         if (!ok) {
             (void)hipGetLastError();             // no masked queues here: the plain order is used
-            for (int lane = 0; lane < 2; ++lane) {
+            for (int lane = 0; lane < RT_FRAME_LANES; ++lane) {
                 if (m.shadow[lane]) (void)hipStreamDestroy(m.shadow[lane]);
                 if (m.chain[lane]) (void)hipStreamDestroy(m.chain[lane]);
                 m.shadow[lane] = m.chain[lane] = nullptr;
@@ -1015,13 +1015,15 @@ static bool overlap_streams_ready(RtContext *ctx)
         m.few = few;
     }
     m.users += 1;
-    // (a context asks from inside a frame lane's scope, where its lane-0 fields are swapped with its lane-1 fields: both sets
-    //  are filled either way round)
-    const bool swapped = ctx->spillArea == 2;
-    (swapped ? ctx->streamShadow1 : ctx->streamShadow) = m.shadow[0];
-    (swapped ? ctx->streamChain1 : ctx->streamChain) = m.chain[0];
-    (swapped ? ctx->streamShadow : ctx->streamShadow1) = m.shadow[1];
-    (swapped ? ctx->streamChain : ctx->streamChain1) = m.chain[1];
+    // (a context may ask from inside the scope of frame lane k >= 1, where its lane-0 fields are swapped with entry k: every
+    //  lane's pair is filled whichever way round)
+    const uint32_t k = ctx->scopeLane;
+    for (uint32_t lane = 0; lane < RT_FRAME_LANES; ++lane) {
+        hipStream_t &sh = lane == k ? ctx->streamShadow : (lane == 0 ? ctx->laneShadow[k] : ctx->laneShadow[lane]);
+        hipStream_t &ch = lane == k ? ctx->streamChain : (lane == 0 ? ctx->laneChain[k] : ctx->laneChain[lane]);
+        sh = m.shadow[lane];
+        ch = m.chain[lane];
+    }
     ctx->overlapCUs = m.few;
     return true;
 }
@@ -1031,18 +1033,19 @@ void rt_release_overlap_streams(RtContext *ctx)
     if (!ctx->overlapCUs) return;
     std::lock_guard<std::mutex> lock(g_maskedMutex);
     RtMaskedStreams &m = g_masked[ctx->device];
-    for (int lane = 0; lane < 2; ++lane) {
+    for (int lane = 0; lane < RT_FRAME_LANES; ++lane) {
         (void)hipStreamSynchronize(m.shadow[lane]);
         (void)hipStreamSynchronize(m.chain[lane]);
     }
     if (--m.users == 0) {
-        for (int lane = 0; lane < 2; ++lane) {
+        for (int lane = 0; lane < RT_FRAME_LANES; ++lane) {
             (void)hipStreamDestroy(m.shadow[lane]);
             (void)hipStreamDestroy(m.chain[lane]);
         }
         m = RtMaskedStreams();
     }
-    ctx->streamShadow = ctx->streamChain = ctx->streamShadow1 = ctx->streamChain1 = nullptr;
+    ctx->streamShadow = ctx->streamChain = nullptr;
+    for (int lane = 0; lane < RT_FRAME_LANES; ++lane) ctx->laneShadow[lane] = ctx->laneChain[lane] = nullptr;
     ctx->overlapCUs = 0;
 }
 
@@ -1201,7 +1204,7 @@ static int overlap_choice(RtContext *ctx, bool shared)
 
 // While alive, every per-path buffer of the context points `firstFrame` frames further on, work goes to
 // `stream`, the queue counters to `counters` and deep stack levels to spill area `area`: the launch helpers then work
-// on a sub-range of the frames in flight without knowing it.  frameLane: the scope is the second lane of the per-frame
+// on a sub-range of the frames in flight without knowing it.  frameLane k >= 1: the scope is lane k of the per-frame
 // call sequence, which also has events and masked streams of its own (swapped with lane 0's while the scope lives).
 struct RtLaneScope {
     RtContext *ctx;
@@ -1212,10 +1215,10 @@ struct RtLaneScope {
     uint32_t *smq, *cnt;
     uint8_t *smFlags;
     float *seeds;
-    bool frameLane;
-    RtLaneScope(RtContext *c, hipStream_t s, uint32_t firstFrame, uint32_t *counters, uint32_t area = 1, bool secondFrameLane = false)
+    uint32_t frameLane;
+    RtLaneScope(RtContext *c, hipStream_t s, uint32_t firstFrame, uint32_t *counters, uint32_t area = 1, uint32_t frameLaneIndex = 0)
         : ctx(c), stream(c->stream), rt(c->dRt), sm(c->dShadowMap), pe(c->dPe), smRec(c->dSmRec), smRecQ(c->dSmRecQ), ray0(c->dRay[0]), ray1(c->dRay[1]), rng(c->dRng),
-          hit(c->dHit), smq(c->dSmQueue), cnt(c->dQCount), smFlags(c->dSmFlags), seeds(c->dSeeds), frameLane(secondFrameLane)
+          hit(c->dHit), smq(c->dSmQueue), cnt(c->dQCount), smFlags(c->dSmFlags), seeds(c->dSeeds), frameLane(frameLaneIndex)
     {
         const size_t off = (size_t)firstFrame * c->tile.nSlots;
         c->stream = s;
@@ -1225,19 +1228,21 @@ struct RtLaneScope {
         c->dQCount = counters;
         c->spillArea = area;     // (two streams of one batch: area 1 -- the overlapped shadow launch, its other user, is off then)
         if (frameLane) swap_lane_fields();
+        c->scopeLane = frameLane;
     }
     void swap_lane_fields()
     {
         RtContext *c = ctx;
-        std::swap(c->evFork, c->evFork1);
-        std::swap(c->evJoin, c->evJoin1);
-        std::swap(c->streamShadow, c->streamShadow1);
-        std::swap(c->streamChain, c->streamChain1);
+        std::swap(c->evFork, c->laneFork[frameLane]);
+        std::swap(c->evJoin, c->laneJoin[frameLane]);
+        std::swap(c->streamShadow, c->laneShadow[frameLane]);
+        std::swap(c->streamChain, c->laneChain[frameLane]);
     }
     ~RtLaneScope()
     {
         RtContext *c = ctx;
         if (frameLane) swap_lane_fields();
+        c->scopeLane = 0;
         c->stream = stream;
         c->dRt = rt; c->dShadowMap = sm; c->dPe = pe; c->dSmRec = smRec; c->dSmRecQ = smRecQ; c->dRng = rng; c->dHit = hit;
         c->dRay[0] = ray0; c->dRay[1] = ray1; c->dSmQueue = smq; c->dQCount = cnt; c->dSmFlags = smFlags; c->dSeeds = seeds;
@@ -1255,7 +1260,8 @@ struct RtLaneScope {
 // built in frame order with the same operations -- same bits as one frame after the other.
 static bool lanes_active(RtContext *ctx)
 {
-    return ctx->optPipelineFrames && !ctx->countersOn && !ctx->timingOn && !ctx->optTwoStreams && ctx->stream2 && ctx->batchCap >= 2 &&
+    return ctx->optPipelineFrames >= 2 && !ctx->countersOn && !ctx->timingOn && !ctx->optTwoStreams && ctx->stream2 &&
+           ctx->batchCap >= (uint32_t)ctx->optPipelineFrames &&
            !(ctx->params.flags & RT_FLAG_BRUTE_FORCE);
 }
 
@@ -1264,15 +1270,15 @@ struct RtFrameLane {
     RtLaneScope *scope = nullptr;
     RtFrameLane(RtContext *ctx, uint32_t lane)
     {
-        if (lane == 1u) {
-            if (!ctx->lane1Busy) {
+        if (lane >= 1u) {
+            if (!ctx->laneBusy[lane]) {
                 // the lane starts up (again): after everything lane 0's stream holds so far -- a batch of rt_render_frames
-                // may still be at work in the frame of path state that is lane 1's
-                (void)hipEventRecord(ctx->evLane1Idle, ctx->stream);
-                (void)hipStreamWaitEvent(ctx->stream2, ctx->evLane1Idle, 0);
+                // may still be at work in the frame of path state that is this lane's
+                (void)hipEventRecord(ctx->evLaneIdle[lane], ctx->stream);
+                (void)hipStreamWaitEvent(ctx->laneStream[lane], ctx->evLaneIdle[lane], 0);
             }
-            scope = new (room) RtLaneScope(ctx, ctx->stream2, 1, ctx->dQCount + CNT_WORDS, 2, true);
-            ctx->lane1Busy = true;
+            scope = new (room) RtLaneScope(ctx, ctx->laneStream[lane], lane, ctx->dQCount + lane * CNT_WORDS, 2u * lane, lane);
+            ctx->laneBusy[lane] = true;
         }
     }
     RtFrameLane(const RtFrameLane &) = delete;
@@ -1286,10 +1292,12 @@ struct RtFrameLane {
 int rt_join_lanes(RtContext *ctx)
 {
     ctx->nextLane = 0;
-    if (!ctx->lane1Busy) return RT_OK;
-    RT_HIP(ctx, hipEventRecord(ctx->evLane1Idle, ctx->stream2));
-    RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evLane1Idle, 0));
-    ctx->lane1Busy = false;
+    for (uint32_t lane = 1; lane < RT_FRAME_LANES; ++lane) {
+        if (!ctx->laneBusy[lane]) continue;
+        RT_HIP(ctx, hipEventRecord(ctx->evLaneIdle[lane], ctx->laneStream[lane]));
+        RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evLaneIdle[lane], 0));
+        ctx->laneBusy[lane] = false;
+    }
     return RT_OK;
 }
 
@@ -1316,7 +1324,7 @@ int rt_dispatch_impl(RtContext *ctx)
     if (rc) return rc;
     const uint32_t laneOfFrame = lanes_active(ctx) ? ctx->nextLane : 0u;
     if (!lanes_active(ctx) && (rc = rt_join_lanes(ctx))) return rc;
-    ctx->nextLane = lanes_active(ctx) ? laneOfFrame ^ 1u : 0u;
+    ctx->nextLane = lanes_active(ctx) ? (laneOfFrame + 1u) % (uint32_t)ctx->optPipelineFrames : 0u;
     ctx->frameLane = laneOfFrame;
     {
         RtFrameLane lane(ctx, laneOfFrame);
@@ -1370,14 +1378,16 @@ static int accumulate_frames(RtContext *ctx, uint32_t frames, uint32_t samplePer
 int rt_accumulate_impl(RtContext *ctx, uint32_t samplePerPixel, int useShadowMap)
 {
     const uint32_t laneOfFrame = ctx->frameLane;
-    const size_t frame = laneOfFrame == 1u ? 0u : ctx->lastFrame;     // (lane 1's scope has moved the frame pointers on already)
+    const size_t frame = laneOfFrame >= 1u ? 0u : ctx->lastFrame;     // (the scope of a lane >= 1 has moved the frame pointers on already)
     RtFrameLane lane(ctx, laneOfFrame);
-    // the running mean is built in frame order: this fold after the fold of the frame before, which the other lane made
-    if (ctx->accumulatedPending[laneOfFrame ^ 1u]) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evAccumulated[laneOfFrame ^ 1u], 0));
+    // the running mean is built in frame order: this fold after the fold of the frame before, which another lane made
+    const uint32_t before = ctx->lastFoldLane;
+    if (before != laneOfFrame && ctx->accumulatedPending[before]) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evAccumulated[before], 0));
     const int rc = accumulate_frames(ctx, 1, samplePerPixel, useShadowMap, frame);
     if (rc) return rc;
     RT_HIP(ctx, hipEventRecord(ctx->evAccumulated[laneOfFrame], ctx->stream));
     ctx->accumulatedPending[laneOfFrame] = true;
+    ctx->lastFoldLane = laneOfFrame;
     return RT_OK;
 }
 
@@ -1418,20 +1428,20 @@ int rt_render_frames_impl(RtContext *ctx, const float *seeds, uint32_t nFrames)
         const uint32_t fA = (ctx->optTwoStreams && f >= 2 && ctx->stream2) ? (f + 1) / 2 : f, fB = f - fA;
         if (fB) {
             // the second stream starts after the seeds are up (and, by stream order, after the last batch was folded in)
-            RT_HIP(ctx, hipEventRecord(ctx->evLane1Idle, ctx->stream));
-            RT_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->evLane1Idle, 0));
+            RT_HIP(ctx, hipEventRecord(ctx->evLaneIdle[1], ctx->stream));
+            RT_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->evLaneIdle[1], 0));
             {
                 // (2: a frame lane of its own -- masked streams, events, spill areas -- so that its shadow rays overlap its bounces too)
                 const bool ownLane = ctx->optTwoStreams == 2;
-                RtLaneScope lane(ctx, ctx->stream2, fA, ctx->dQCount + CNT_WORDS, ownLane ? 2u : 1u, ownLane);
+                RtLaneScope lane(ctx, ctx->stream2, fA, ctx->dQCount + CNT_WORDS, ownLane ? 2u : 1u, ownLane ? 1u : 0u);
                 rc = render_lane(ctx, fB, matte, shared);
             }
             if (rc) return rc;
         }
         if ((rc = render_lane(ctx, fA, matte, shared))) return rc;
         if (fB) {
-            RT_HIP(ctx, hipEventRecord(ctx->evLane1Idle, ctx->stream2));
-            RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evLane1Idle, 0));
+            RT_HIP(ctx, hipEventRecord(ctx->evLaneIdle[1], ctx->stream2));
+            RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evLaneIdle[1], 0));
         }
         ctx->lastFrame = f - 1;
         if ((rc = accumulate_frames(ctx, f, ctx->sampleCount, matte ? 1 : 0, 0))) return rc;
@@ -1450,16 +1460,19 @@ int rt_readback_async_impl(RtContext *ctx, const float4 *src, float *pinnedDst)
     const uint32_t laneOfFrame = ctx->frameLane;
     const size_t px = (size_t)ctx->params.width * ctx->params.height;
     RtFrameLane lane(ctx, laneOfFrame);
-    if (ctx->copyPending) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evCopied, 0));      // the staging frame is still being read
-    if (ctx->tile.count > 1) RT_HIP(ctx, hipMemsetAsync(ctx->dReadbackFull, 0, px * sizeof(float4), ctx->stream));   // other ranks' pixels read 0
-    const int rc = rt_expand_local_impl(ctx, src, ctx->dReadbackFull);
+    const uint32_t slot = ctx->readbackSlot;
+    ctx->readbackSlot ^= 1u;
+    float4 *staging = ctx->dReadbackFull + (size_t)slot * (px ? px : 1);
+    if (ctx->copyPending[slot]) RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evCopied[slot], 0));      // this staging frame is still being read
+    if (ctx->tile.count > 1) RT_HIP(ctx, hipMemsetAsync(staging, 0, px * sizeof(float4), ctx->stream));   // other ranks' pixels read 0
+    const int rc = rt_expand_local_impl(ctx, src, staging);
     if (rc) return rc;
     RT_HIP(ctx, hipEventRecord(ctx->evExpanded, ctx->stream));
     if (ctx->accumulatedPending[laneOfFrame]) RT_HIP(ctx, hipEventRecord(ctx->evAccumulated[laneOfFrame], ctx->stream));
     RT_HIP(ctx, hipStreamWaitEvent(ctx->streamCopy, ctx->evExpanded, 0));
-    RT_HIP(ctx, hipMemcpyAsync(pinnedDst, ctx->dReadbackFull, px * sizeof(float4), hipMemcpyDeviceToHost, ctx->streamCopy));
-    RT_HIP(ctx, hipEventRecord(ctx->evCopied, ctx->streamCopy));
-    ctx->copyPending = true;
+    RT_HIP(ctx, hipMemcpyAsync(pinnedDst, staging, px * sizeof(float4), hipMemcpyDeviceToHost, ctx->streamCopy));
+    RT_HIP(ctx, hipEventRecord(ctx->evCopied[slot], ctx->streamCopy));
+    ctx->copyPending[slot] = true;
     return RT_OK;
 }
 

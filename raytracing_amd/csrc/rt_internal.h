@@ -193,7 +193,10 @@ struct RtPendingEvent {
     hipEvent_t start, stop;
 };
 
-#define RT_COUNTER_BLOCK_WORDS 1536 // queue counts and ray cursors (dQCount), a 128-byte line each, one set per stream
+#ifndef RT_FRAME_LANES
+#define RT_FRAME_LANES 4
+#endif
+#define RT_COUNTER_BLOCK_WORDS (768 * RT_FRAME_LANES) // queue counts and ray cursors (dQCount), a 128-byte line each, one set per lane
 #define RT_SPILL_WORDS_PER_CU (2048 * RT_STACK_DEPTH)   // room for every stack level of 2048 lanes per CU
 #define RT_NONCASTER_LIST 8                             // non-casting triangles a shadow ray is tested against one by one
 // A reference to a child in a two-level record (RtQNode4): bit 31 leaf, bit 30 "the subtree holds a large triangle" (the bounded
@@ -207,7 +210,7 @@ struct RtPendingEvent {
 // the point o + t'd of a triangle the reference accepts lies within RT_BOUND_C x |e1||e2| x |o - v0| x |d| of the triangle
 // (derivation in rt_traverse.h: 28.9 unit roundoffs over the reference's smallest determinant, 1e-8, is 172.3)
 #define RT_BOUND_C 192.0f
-#define RT_SPILL_AREAS 4                                // walker launches that may be on the chip together: per frame lane (two), the
+#define RT_SPILL_AREAS (2 * RT_FRAME_LANES)                                // walker launches that may be on the chip together: per frame lane (two), the
                                                         // launches of its own stream and the shadow-ray launch that overlaps them
 
 struct RtPostState;   // post.hip
@@ -218,17 +221,20 @@ struct RtContext {
     hipStream_t stream2 = nullptr;        // second half of the frames in flight (rt_render_frames); every other frame of the per-frame calls
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     hipStream_t streamShadow = nullptr, streamChain = nullptr;   // queues masked to most / the remaining few compute units (process-wide)
-    // Two frames of the per-frame call sequence in flight (RT_OPT_PIPELINE_FRAMES): frames alternate between two lanes, each
-    // with its own stream, masked streams, events, frame of path state, counter block and spill areas.  The fields above are
-    // lane 0's; while lane 1's calls are made they are swapped for these (RtLaneScope).
-    hipEvent_t evFork1 = nullptr, evJoin1 = nullptr;
-    hipStream_t streamShadow1 = nullptr, streamChain1 = nullptr;
-    hipEvent_t evAccumulated[2] = {nullptr, nullptr};   // after a lane's rt_accumulate: the next frame's fold waits for it
-    hipEvent_t evLane1Idle = nullptr;
-    bool accumulatedPending[2] = {false, false};
-    bool lane1Busy = false;               // lane 1's stream may hold work that lane 0's stream has not waited for
-    bool optPipelineFrames = true;
+    // Several frames of the per-frame call sequence in flight (RT_OPT_PIPELINE_FRAMES): frames go round RT_FRAME_LANES lanes, each
+    // with its own stream, masked streams, events, frame of path state, counter block and pair of spill areas.  The fields
+    // above are lane 0's; while the calls of lane k >= 1 are made they are swapped for entry k of these (RtLaneScope).
+    hipStream_t laneStream[RT_FRAME_LANES] = {};      // [1] is stream2
+    hipEvent_t laneFork[RT_FRAME_LANES] = {}, laneJoin[RT_FRAME_LANES] = {};
+    hipStream_t laneShadow[RT_FRAME_LANES] = {}, laneChain[RT_FRAME_LANES] = {};
+    hipEvent_t evAccumulated[RT_FRAME_LANES] = {};    // after a lane's rt_accumulate: the next frame's fold waits for it
+    hipEvent_t evLaneIdle[RT_FRAME_LANES] = {};
+    bool accumulatedPending[RT_FRAME_LANES] = {};
+    bool laneBusy[RT_FRAME_LANES] = {};               // the lane's stream may hold work that lane 0's stream has not waited for
+    int optPipelineFrames = RT_FRAME_LANES;           // lanes in use (1: the per-frame calls go down one stream)
     uint32_t frameLane = 0, nextLane = 0; // the lane of the frame rt_dispatch last started, and of the next one
+    uint32_t lastFoldLane = 0;            // the lane whose rt_accumulate came last
+    uint32_t scopeLane = 0;               // the frame lane whose fields are swapped in right now (RtLaneScope)
     hipStream_t streamMain = nullptr;     // the caller's stream while ctx->stream is the chain stream
     uint32_t overlapCUs = 0;              // the split the two masked streams were made for (0: none held)
     bool overlapTried = false;
@@ -331,8 +337,9 @@ struct RtContext {
     float4 *dReadbackFull = nullptr;
     size_t readbackPixels = 0;
     hipStream_t streamCopy = nullptr;
-    hipEvent_t evExpanded = nullptr, evCopied = nullptr;
-    bool copyPending = false;
+    hipEvent_t evExpanded = nullptr, evCopied[2] = {nullptr, nullptr};   // two staging frames in dReadbackFull, used in turn:
+    bool copyPending[2] = {false, false};                                 // a frame is expanded while the one before is copied out
+    uint32_t readbackSlot = 0;
 
     RtPostState *post = nullptr;          // images and scratch of the post-process chain, made on first use
 };

@@ -694,8 +694,8 @@ def test_shadowmap_pass_started_by_dispatch_gives_the_same_bits(core):
 
 @pytest.mark.parametrize("scene", ["car with ShadowMap pass", "cornell"])
 def test_two_frames_in_flight_through_the_per_frame_calls_keep_the_bits(core, scene):
-    """The per-frame call sequence keeps two frames in flight (RT_OPT_PIPELINE_FRAMES): the images after every frame and
-    at the end are those of one frame after the other, and of the batch call."""
+    """The per-frame call sequence keeps up to four frames in flight (RT_OPT_PIPELINE_FRAMES: 2, 3, or 1 = 4 lanes): the
+    images after every frame and at the end are those of one frame after the other, and of the batch call."""
     if scene == "cornell":
         sc = scenes.cornell_box(320, 200, sphere_segments=24)
     else:
@@ -725,11 +725,12 @@ def test_two_frames_in_flight_through_the_per_frame_calls_keep_the_bits(core, sc
     names = ("rt", "shadow map", "converged")
     try:
         want_frames = run(0, peek=True)
-        for upto in (7, 6, 1):                         # the last frame on either lane
-            got = run(1, upto=upto)
-            for name, a, b in zip(names, got, want_frames[upto - 1]):
-                if name != "shadow map" or use_shadow:
-                    H.assert_bits_equal(a, b, f"{name} after {upto} frames, two frames in flight")
+        for lanes in (1, 2, 3):                        # (1: as many as the library has, four)
+            for upto in (7, 6, 5, 4, 1):               # the last frame on any lane
+                got = run(lanes, upto=upto)
+                for name, a, b in zip(names, got, want_frames[upto - 1]):
+                    if name != "shadow map" or use_shadow:
+                        H.assert_bits_equal(a, b, f"{name} after {upto} frames, RT_OPT_PIPELINE_FRAMES {lanes}")
         got_frames = run(1, peek=True)
         for k, (g, w) in enumerate(zip(got_frames, want_frames)):
             for name, a, b in zip(names, g, w):
