@@ -1250,12 +1250,12 @@ struct RtLaneScope {
     }
 };
 
-// ---- two frames of the per-frame call sequence in flight (RT_OPT_PIPELINE_FRAMES)
+// ---- several frames of the per-frame call sequence in flight (RT_OPT_PIPELINE_FRAMES)
 // A host that keeps the reference's loop calls rt_set_params (new seed), rt_dispatch, rt_dispatch_shadowmap, rt_accumulate
 // once per frame (RayTracing.cs:118-164).  One frame by itself is a chain of two dozen launches most of which are as
-// long as their longest ray and leave the chip nearly idle; so consecutive frames go down two lanes -- two streams, two
-// frames of path state, two counter blocks, their own masked streams and spill areas -- and the launches of frame k + 1
-// fill the idle time of frame k's.  What orders them is data: a lane's stream keeps its own frames in order, and the
+// long as their longest ray and leave the chip nearly idle; so consecutive frames go round
+// RT_FRAME_LANES lanes -- each with a stream, a frame of path state, a counter block, masked streams and spill areas of
+// its own -- and the launches of the frames after frame k fill the idle time of frame k's.  What orders them is data: a lane's stream keeps its own frames in order, and the
 // fold of a frame into the running mean waits for the fold of the frame before it (evAccumulated), so the mean is
 // built in frame order with the same operations -- same bits as one frame after the other.
 static bool lanes_active(RtContext *ctx)

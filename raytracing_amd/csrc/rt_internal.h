@@ -304,9 +304,9 @@ struct RtContext {
     bool optCasterBox = true;             // shadow rays that cannot meet a shadow caster are not walked
     bool optFirstHitShadow = true;        // shadow rays that cannot meet a non-casting triangle stop at their first hit
     bool optOverlapShadow = true;         // walk the shadow rays while the later bounces run (render.hip, overlap_fork)
-    int optPruneByDistance = 1;
-    float smallEdgeProduct = 0.0f, smallEdgeSum = 0.0f;   // largest |e1||e2| and |e1| + |e2| among the scene's small triangles (0: none)           // RT_OPT_PRUNE_BY_DISTANCE: boxes beyond the closest hit found so far are not entered by 0 no ray, 1 the rays
-                                          // whose hits are not handed out (bounce rays, soft-shadow rays), 2 every ray
+    int optPruneByDistance = 1;           // RT_OPT_PRUNE_BY_DISTANCE: 0 no box is left out, 1 what the bounded rule allows (exact), 2 what begins
+                                          // 1.5 % beyond the closest hit
+    float smallEdgeProduct = 0.0f, smallEdgeSum = 0.0f;   // largest |e1||e2| and |e1| + |e2| among the scene's small triangles (0: none)
     bool optShareLongWalks = true;        // idle lanes take over parts of the walks a launch ends with (RT_OPT_SHARE_LONG_WALKS)
     bool optEagerShadowMap = true;        // rt_dispatch starts the ShadowMap pass of its frame (render.hip, rt_dispatch_impl)
     int eagerShadow = 0;                  // RT_EAGER_*: what rt_dispatch left for rt_dispatch_shadowmap
