@@ -490,7 +490,7 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *                          frames in flight: consecutive frames go round four lanes (stream, frame of path state, counter
  *                          block, masked streams, spill areas of their own), so the launches of a frame fill the idle time
  *                          of the frames before, most of whose launches are as long as their longest ray (one frame at a
- *                          time 4.2 ms, two lanes 3.0, three 2.6, four 2.4; six and eight lanes are slower again).  The folds
+ *                          time 4.2 ms, two lanes 3.0, three 2.6, four 2.4 -- 2.15 with RT_OPT_OVERLAP_CUS as it is chosen for them; six and eight lanes are slower again).  The folds
  *                          into the running mean stay in frame order (each waits for the one before), so the images keep
  *                          their bits; RT_IMAGE_RT / RT_IMAGE_SHADOWMAP show the frame of the last rt_dispatch.  Any call
  *                          other than those four (and rt_set_dirty) first lets all lanes run out.  2, 3, 4: that many
@@ -498,9 +498,10 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  *                          RT_OPT_TWO_STREAMS and with the brute-force flag.
  *   RT_OPT_OVERLAP_AFTER   0..6, default 0: the bounce whose extend launch the overlap starts after (0: as soon as the
  *                          primary hits are known)
- *   RT_OPT_OVERLAP_CUS     compute units the bounce launches keep meanwhile, default 64 (multiples of 32 measured best);
- *                          read when a context first renders that way, and the contexts of a process that render on the
- *                          same device share the first one's split */
+ *   RT_OPT_OVERLAP_CUS     compute units the bounce launches keep meanwhile (multiples of 32 measured best); default 0: 64 of
+ *                          256, or 96 where the call has few paths in flight (under 24 M -- the per-frame calls above all:
+ *                          the bounce chain is then what a frame waits for).  The masked streams of a split are made when
+ *                          a context first renders with it and are shared by the contexts of the process on that device */
 #define RT_OPT_PACKET_SHADOW 0
 #define RT_OPT_PACKET_PRIMARY 1
 #define RT_OPT_PACKET_TRACE 2

@@ -786,7 +786,7 @@ int rt_set_option(RtContext *ctx, int option, int value)
         ctx->optOverlapAfter = (uint32_t)value;
         return RT_OK;
     case RT_OPT_OVERLAP_CUS:
-        if (value < 1 || value >= ctx->numCU) return rt_fail(ctx, RT_E_INVALID, "RT_OPT_OVERLAP_CUS must be 1..compute units - 1");
+        if (value < 0 || value >= ctx->numCU) return rt_fail(ctx, RT_E_INVALID, "RT_OPT_OVERLAP_CUS must be 0 (the library chooses) .. compute units - 1");
         ctx->optOverlapCUs = (uint32_t)value;
         return RT_OK;
     case RT_OPT_BATCH_FRAMES:

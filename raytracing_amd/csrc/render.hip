@@ -17,6 +17,7 @@
 #include "rt_internal.h"
 #include "rt_shade.h"
 
+#include <algorithm>
 #include "rt_traverse.h"
 #include "rt_brute.h"
 
@@ -977,25 +978,32 @@ static uint32_t walker_blocks_per_cu()
     return (uint32_t)perCU;
 }
 
-// The two masked queues of a device are shared by the contexts of the process that render on it and go
-// when the last of those contexts is destroyed; the split is the one the first of them asked for.
+// The masked queues of a device -- a set per unit split that was asked for, a pair per frame lane in each -- are shared by
+// the contexts of the process that render on it; a set goes when the last context that used it is destroyed.
 struct RtMaskedStreams {
-    uint32_t few = 0, users = 0;
+    uint32_t users = 0;
     hipStream_t shadow[RT_FRAME_LANES] = {}, chain[RT_FRAME_LANES] = {};   // a pair per frame lane, same masks
 };
 static std::mutex g_maskedMutex;
-static std::map<int, RtMaskedStreams> g_masked;
+static std::map<std::pair<int, uint32_t>, RtMaskedStreams> g_masked;       // by (device, units of the bounce chain)
 
-static bool overlap_streams_ready(RtContext *ctx)
+// paths: what the call that asks has in flight.  Units for the bounce chain: 64 of 256 where the shadow launch is what the
+// step waits for (the whole 1080p image with 64 frames in flight: 64 / 96 / 128 units give 86.3 / 87.0 / 87.7 ms; a quarter
+// of it: 24.8 / 25.5 / 26.1).  A small batch -- the frames of the per-frame calls above all -- waits for the chain instead,
+// whose launches last as long as their longest rays however few there are: it gets 96 (four frames of the per-frame
+// calls in flight: 2.42 / 2.16 / 2.27 ms per frame with 64 / 96 / 112; an eighth of the 64-frame batch: no difference).
+// A context changes sets only between frames (its callers see to that: no ShadowMap pass is under way), and the work it
+// queued on the old set's streams has been ordered into its own streams by then.
+static bool overlap_streams_ready(RtContext *ctx, size_t paths)
 {
-    if (ctx->overlapTried) return ctx->overlapCUs != 0;
-    ctx->overlapTried = true;
+    const uint32_t n = (uint32_t)ctx->numCU;
+    const uint32_t few = ctx->optOverlapCUs ? ctx->optOverlapCUs : (paths < ((size_t)24 << 20) && n >= 192u ? 96u : (n >= 128u ? 64u : n / 4u));
+    if (few == ctx->overlapCUs) return true;
+    if (few < 1 || few >= n || ctx->overlapFailed) return false;
     std::lock_guard<std::mutex> lock(g_maskedMutex);
-    RtMaskedStreams &m = g_masked[ctx->device];
+    RtMaskedStreams &m = g_masked[std::make_pair(ctx->device, few)];
+    const bool mine = std::find(ctx->overlapSets.begin(), ctx->overlapSets.end(), few) != ctx->overlapSets.end();
     if (m.users == 0) {
-        const uint32_t n = (uint32_t)ctx->numCU;
-        const uint32_t few = ctx->optOverlapCUs;
-        if (few < 1 || few >= n) return false;
         const uint32_t words = (n + 31u) / 32u;
         std::vector<uint32_t> most(words, 0u), rest(words, 0u);
         for (uint32_t cu = 0; cu < n; ++cu) (cu < n - few ? most : rest)[cu >> 5] |= 1u << (cu & 31u);
@@ -1010,11 +1018,14 @@ static bool overlap_streams_ready(RtContext *ctx)
                 if (m.chain[lane]) (void)hipStreamDestroy(m.chain[lane]);
                 m.shadow[lane] = m.chain[lane] = nullptr;
             }
+            ctx->overlapFailed = true;
             return false;
         }
-        m.few = few;
     }
-    m.users += 1;
+    if (!mine) {
+        m.users += 1;
+        ctx->overlapSets.push_back(few);
+    }
     // (a context may ask from inside the scope of frame lane k >= 1, where its lane-0 fields are swapped with entry k: every
     //  lane's pair is filled whichever way round)
     const uint32_t k = ctx->scopeLane;
@@ -1024,26 +1035,28 @@ static bool overlap_streams_ready(RtContext *ctx)
         sh = m.shadow[lane];
         ch = m.chain[lane];
     }
-    ctx->overlapCUs = m.few;
+    ctx->overlapCUs = few;
     return true;
 }
 
 void rt_release_overlap_streams(RtContext *ctx)
 {
-    if (!ctx->overlapCUs) return;
     std::lock_guard<std::mutex> lock(g_maskedMutex);
-    RtMaskedStreams &m = g_masked[ctx->device];
-    for (int lane = 0; lane < RT_FRAME_LANES; ++lane) {
-        (void)hipStreamSynchronize(m.shadow[lane]);
-        (void)hipStreamSynchronize(m.chain[lane]);
-    }
-    if (--m.users == 0) {
+    for (const uint32_t few : ctx->overlapSets) {
+        RtMaskedStreams &m = g_masked[std::make_pair(ctx->device, few)];
         for (int lane = 0; lane < RT_FRAME_LANES; ++lane) {
-            (void)hipStreamDestroy(m.shadow[lane]);
-            (void)hipStreamDestroy(m.chain[lane]);
+            (void)hipStreamSynchronize(m.shadow[lane]);
+            (void)hipStreamSynchronize(m.chain[lane]);
         }
-        m = RtMaskedStreams();
+        if (--m.users == 0) {
+            for (int lane = 0; lane < RT_FRAME_LANES; ++lane) {
+                (void)hipStreamDestroy(m.shadow[lane]);
+                (void)hipStreamDestroy(m.chain[lane]);
+            }
+            m = RtMaskedStreams();
+        }
     }
+    ctx->overlapSets.clear();
     ctx->streamShadow = ctx->streamChain = nullptr;
     for (int lane = 0; lane < RT_FRAME_LANES; ++lane) ctx->laneShadow[lane] = ctx->laneChain[lane] = nullptr;
     ctx->overlapCUs = 0;
@@ -1192,12 +1205,12 @@ static int upload_seeds(RtContext *ctx, const float *seeds, uint32_t n)
     return RT_OK;
 }
 
-static int overlap_choice(RtContext *ctx, bool shared)
+static int overlap_choice(RtContext *ctx, bool shared, uint32_t frames)
 {
     // Per-launch counters and event timers describe launches of one stream, one after the other: both keep the plain order.
     if (shared && ctx->optOverlapShadow && ctx->optTwoStreams != 1 && !ctx->countersOn && !ctx->timingOn && !ctx->optPacketShadow &&
         !(ctx->params.flags & RT_FLAG_BRUTE_FORCE) && ctx->tile.nSlots != 0 && ctx->optOverlapAfter + 1 < RT_MAX_BOUNCE &&
-        overlap_streams_ready(ctx))
+        overlap_streams_ready(ctx, (size_t)ctx->tile.nSlots * frames))
         return (int)ctx->optOverlapAfter;
     return -1;
 }
@@ -1334,7 +1347,7 @@ int rt_dispatch_impl(RtContext *ctx)
         if (!eager) {
             rc = dispatch_frames(ctx, 1, false);
         } else {
-            const int overlapAfter = overlap_choice(ctx, true);
+            const int overlapAfter = overlap_choice(ctx, true, 1);
             rc = dispatch_frames(ctx, 1, true, overlapAfter);
             const int rc2 = overlap_chain_done(ctx);
             if (!rc) rc = rc2;
@@ -1393,7 +1406,7 @@ int rt_accumulate_impl(RtContext *ctx, uint32_t samplePerPixel, int useShadowMap
 
 static int render_lane(RtContext *ctx, uint32_t frames, bool matte, bool shared)
 {
-    const int overlapAfter = overlap_choice(ctx, shared);
+    const int overlapAfter = overlap_choice(ctx, shared, frames);
     int rc = dispatch_frames(ctx, frames, shared, overlapAfter);
     if (rc || !matte) {
         if (ctx->streamMain) {                   // left the bounce loop on the chain stream

@@ -236,8 +236,9 @@ struct RtContext {
     uint32_t lastFoldLane = 0;            // the lane whose rt_accumulate came last
     uint32_t scopeLane = 0;               // the frame lane whose fields are swapped in right now (RtLaneScope)
     hipStream_t streamMain = nullptr;     // the caller's stream while ctx->stream is the chain stream
-    uint32_t overlapCUs = 0;              // the split the two masked streams were made for (0: none held)
-    bool overlapTried = false;
+    uint32_t overlapCUs = 0;              // the split of the masked streams in use (0: none yet)
+    std::vector<uint32_t> overlapSets;    // the splits whose process-wide sets of masked streams this context holds a share of
+    bool overlapFailed = false;           // the runtime refused masked streams: the plain order is used
     std::string err;
 
     // inputs
@@ -311,7 +312,7 @@ struct RtContext {
     bool optEagerShadowMap = true;        // rt_dispatch starts the ShadowMap pass of its frame (render.hip, rt_dispatch_impl)
     int eagerShadow = 0;                  // RT_EAGER_*: what rt_dispatch left for rt_dispatch_shadowmap
     uint32_t optOverlapAfter = 0;         // ... from the extend launch of this bounce on
-    uint32_t optOverlapCUs = 64;          // compute units the bounce launches keep meanwhile
+    uint32_t optOverlapCUs = 0;           // compute units the bounce launches keep meanwhile (0: 64, or 96 for a small batch; render.hip)
     uint32_t optBatchFrames = 0;          // 0 = by path count (rt_batch_frames)
     uint32_t batchCap = 0;                // frames the path-state buffers can hold
     uint32_t lastFrame = 0;               // frame of the batch that RT_IMAGE_RT / RT_IMAGE_SHADOWMAP show
