@@ -112,6 +112,56 @@ def test_rays_in_the_planes_of_the_cars_own_triangles(core, oracle):
     core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 1)
 
 
+def test_a_scene_of_large_and_small_triangles_side_by_side(core, oracle):
+    """The Cornell box at 1/24 of its size: the two spheres' 16 000 triangles are small ones for the bounded rule, the
+    walls, the boxes and the lamp are large and keep their flag up the tree -- first hits of rays between random points
+    of the room and of camera rays against the checker, with the rule at work on the spheres."""
+    import copy
+    from raytracing_amd import scenes
+    sc = copy.deepcopy(scenes.cornell_box(64, 64, sphere_segments=64))
+    scale = 1.0 / 24.0
+    sc.vertices["position"] *= np.float32(scale)
+    v = np.asarray(sc.vertices["position"], np.float64)
+    idx = np.asarray(sc.indices, np.int64).reshape(-1, 3)
+    e1 = np.linalg.norm(v[idx[:, 1]] - v[idx[:, 0]], axis=1)
+    e2 = np.linalg.norm(v[idx[:, 2]] - v[idx[:, 0]], axis=1)
+    small = (e1 * e2 <= 2.0 ** -12) & (e1 + e2 <= 0.25)
+    assert 0.5 < small.mean() < 1.0 and (~small).sum() >= 10
+    lo, hi = v.min(axis=0), v.max(axis=0)
+    rs = np.random.Generator(np.random.PCG64(61))
+    a = lo + (hi - lo) * rs.random((400_000, 3))
+    b = lo + (hi - lo) * rs.random((400_000, 3))
+    d = b - a
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o2, d2 = adversarial.rays_in_the_planes_of(sc, 400_000, seed=63, start=(0.01, 0.5))
+    o = np.concatenate([a.astype(np.float32), o2])
+    d = np.concatenate([d.astype(np.float32), d2])
+    orc = oracle.Oracle(sc).build()
+    want = orc.trace(o, d)
+    hit = want["triangle"] != 0xFFFFFFFF
+    assert hit.mean() > 0.9
+    core.upload(sc)
+    core.bvh_build()
+    work = {}
+    core.enable_counters(True)
+    for value in (1, 0):
+        core.set_option(wire.OPT_PRUNE_BY_DISTANCE, value)
+        core.reset_stats()
+        got = core.trace_rays(o, d)
+        work[value] = core.stats()
+        H.assert_bits_equal(got["triangle"], want["triangle"], f"first-hit triangle, option {value}")
+        H.assert_bits_equal(got["t"], want["t"], f"hit distance, option {value}")
+        H.assert_bits_equal(got["u"][hit], want["u"][hit], f"u, option {value}")
+        H.assert_bits_equal(got["v"][hit], want["v"][hit], f"v, option {value}")
+    core.enable_counters(False)
+    core.set_option(wire.OPT_PRUNE_BY_DISTANCE, 1)
+    got = core.trace_rays(o, d)
+    H.assert_bits_equal(got["triangle"], want["triangle"], "first-hit triangle, plain kernel")
+    H.assert_bits_equal(got["t"], want["t"], "hit distance, plain kernel")
+    print(f"\nboxes tested per ray: {work[0]['internalVisits'] / len(o):.1f} without, {work[1]['internalVisits'] / len(o):.1f} with the bounded rule")
+    assert work[1]["internalVisits"] < work[0]["internalVisits"]
+
+
 def test_frames_with_bounce_rays_pruned_are_the_checkers(core, oracle):
     """Whole frames -- camera, bounce and soft-shadow rays -- on a scene of ordinary shapes: the frame is the checker's
     bit for bit with the bounded rule (1, the default), with no box left out (0) and with the 1.5 % rule (2)."""
