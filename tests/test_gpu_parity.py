@@ -922,3 +922,51 @@ def test_equal_distances_go_to_the_reference_first_visited(core, oracle):
         if min(g, key=lambda i: leaf_of[i]) != min(g, key=lambda i: walk["visit_rank"][i]):
             decided += 1
     assert decided > 20
+
+
+def test_unusual_orders_of_the_per_frame_calls_with_frames_in_flight(core):
+    """A host need not keep to dispatch / ShadowMap / accumulate: frames dispatched and never folded, two folds of one frame,
+    a ShadowMap pass without its CSMain, a parameter change in the middle, a first-hit query between two frames.  With
+    four frames in flight the images are those of one frame at a time."""
+    sc = scenes.car_standin(256, 160, detail=0.1)
+    seeds = scenes.frame_seeds(9, seed=71)
+    core.upload(sc)
+    core.bvh_build()
+    o, d = H.camera_rays(sc.params, 16)
+
+    def run(pipeline):
+        core.set_option(wire.OPT_PIPELINE_FRAMES, pipeline)
+        p = sc.params.copy()
+        core.set_params(p)
+        core.set_dirty()
+        out = []
+        k = 0
+        for step, seed in enumerate(seeds):
+            p.seed = float(seed)
+            core.set_params(p)
+            if step != 4:
+                core.dispatch()                      # (step 4: a ShadowMap pass with no CSMain before it)
+            if step == 1:
+                continue                             # dispatched, never folded
+            if step == 6:
+                p.lightParameter[3] = p.lightParameter[3] * 1.5      # the light's radius changes between the two kernels
+                core.set_params(p)
+            core.dispatch_shadowmap()
+            core.accumulate(k, True)
+            k += 1
+            if step == 3:
+                core.accumulate(k, True)             # folded twice
+                k += 1
+            if step == 5:
+                out.append(core.trace_rays(o, d)["t"].copy())        # lets the lanes run out, then goes on
+        out += [core.readback(w) for w in (wire.IMAGE_RT, wire.IMAGE_SHADOWMAP, wire.IMAGE_CONVERGED)]
+        return out
+
+    try:
+        want = run(0)
+        for lanes in (1, 2):
+            got = run(lanes)
+            for name, a, b in zip(("first hits", "rt", "shadow map", "converged"), got, want):
+                H.assert_bits_equal(a, b, f"{name}, RT_OPT_PIPELINE_FRAMES {lanes}")
+    finally:
+        core.set_option(wire.OPT_PIPELINE_FRAMES, 1)
