@@ -143,10 +143,16 @@ typedef struct RtParams {
     float focalLength;
     uint32_t flags;
     /* Image-tile sharding (no counterpart in the reference; single GPU there).
-     * The frame is cut into tileSize x tileSize tiles in row-major order and
-     * this context renders tiles t with t % tileCount == tileRank.  Pixel
+     * The frame is cut into tileSize x tileSize tiles in row-major order; every
+     * group of tileCount consecutive tiles gives one tile to each rank, in an
+     * order turned from group to group by a hash of the group's number, so that
+     * no rank's tiles form columns or diagonals of the image (which tile is a
+     * rank's k-th: rt_local_pixel_map tells, per pixel slot).  Small tiles even
+     * the ranks' loads out: an eighth of the 1080p bench image takes 11.7 ..
+     * 14.5 ms from rank to rank in 64 x 64 tiles, 12.8 .. 13.0 ms in 8 x 8.  Pixel
      * coordinates given to the RNG stay global, so the union of all ranks'
-     * tiles is bit-identical to a single-GPU frame.  tileCount <= 1 = whole frame. */
+     * tiles is bit-identical to a single-GPU frame.  tileCount <= 1 = whole
+     * frame.  tileSize: a multiple of 8, at most 1024; <= 0 = 64. */
     int32_t tileRank, tileCount, tileSize;
 } RtParams;
 

@@ -393,7 +393,7 @@ int rt_set_params(RtContext *ctx, const RtParams *p)
     tm.rank = q.tileRank;
     tm.count = q.tileCount;
     const uint32_t T = (uint32_t)tm.tilesX * (uint32_t)tm.tilesY;
-    tm.nLocalTiles = T > (uint32_t)q.tileRank ? (T - (uint32_t)q.tileRank + (uint32_t)q.tileCount - 1) / (uint32_t)q.tileCount : 0;
+    tm.nLocalTiles = (T + (uint32_t)q.tileCount - 1) / (uint32_t)q.tileCount;   // one of every group of tileCount tiles; in the last group that may be a tile beyond the image (padding)
     tm.nSlots = tm.nLocalTiles * (uint32_t)(q.tileSize * q.tileSize);
     tm.finish();
     // ray indices are 32-bit: 16 shadow rays per path slot of one frame must fit

@@ -151,7 +151,7 @@ struct RtTileMap {
     int rank, count;
     uint32_t nLocalTiles;
     uint32_t nSlots;           // nLocalTiles * tileSize^2
-    RtDivisor byTilePixels, byTilesX, byBlocksPerRow, bySlots;   // tileSize^2, tilesX, tileSize / 8, nSlots (finish())
+    RtDivisor byTilePixels, byTilesX, byBlocksPerRow, bySlots, byCount;   // tileSize^2, tilesX, tileSize / 8, nSlots, count (finish())
 
     void finish()
     {
@@ -159,6 +159,21 @@ struct RtTileMap {
         byTilesX = rt_divisor((uint32_t)tilesX);
         byBlocksPerRow = rt_divisor((uint32_t)tileSize >> 3);
         bySlots = rt_divisor(nSlots);
+        byCount = rt_divisor((uint32_t)count);
+    }
+    // Which tile is the k-th of this rank.  The tiles in row-major order go to the ranks in groups of `count`, one tile
+    // of a group to each rank; the order inside group k is turned by a hash of k, so that no rank's tiles form a lattice
+    // over the image (columns or diagonals of tiles, which one part of a scene can load more than another).
+    __host__ __device__ inline uint32_t tile_of(uint32_t k) const
+    {
+        uint32_t turn, h = k * 2654435761u;
+        h ^= h >> 16;
+        h *= 2246822507u;
+        h ^= h >> 13;
+        byCount.div(h >> 8, &turn);
+        uint32_t r = (uint32_t)rank + turn;
+        if (r >= (uint32_t)count) r -= (uint32_t)count;
+        return k * (uint32_t)count + r;
     }
     // path slot (frame * nSlots + tile-local pixel slot) -> tile-local pixel slot; *frame: which frame in flight
     __host__ __device__ inline uint32_t local_slot(uint32_t pathSlot, uint32_t *frame) const
@@ -171,7 +186,7 @@ struct RtTileMap {
     {
         uint32_t within, tx, bx;
         const uint32_t k = byTilePixels.div(slot, &within);
-        const uint32_t t = k * (uint32_t)count + (uint32_t)rank;
+        const uint32_t t = tile_of(k);              // (beyond the last tile for some k of the last group: y >= height)
         const uint32_t ty = byTilesX.div(t, &tx);
         const uint32_t b = within >> 6, l = within & 63u;
         const uint32_t by = byBlocksPerRow.div(b, &bx);

@@ -58,19 +58,41 @@ def broadcast_scene(sc, device, src=0):
                         out["materials"], out["sphere_lights"], out["area_lights"], out["disc_lights"], out["skybox"], params)
 
 
+def _group_turn(k, world):
+    """By how many places the k-th group of `world` tiles is turned (the hash of
+    RtTileMap::tile_of in csrc/rt_internal.h, in 64-bit integers)."""
+    h = (np.asarray(k, dtype=np.int64) * 2654435761) & 0xFFFFFFFF
+    h ^= h >> 16
+    h = (h * 2246822507) & 0xFFFFFFFF
+    h ^= h >> 13
+    return (h >> 8) % world
+
+
+def tile_owner(t, world):
+    """Rank that renders tile t (row-major tile index; array or int): the
+    inverse of RtTileMap::tile_of in csrc/rt_internal.h."""
+    t = np.asarray(t, dtype=np.int64)
+    turn = _group_turn(t // world, world)
+    return (t % world - turn) % world
+
+
 def tile_pixel_map(width, height, tile_size, rank, world):
     """Global pixel index (y*width+x, PAD for padding) of every tile-local slot of
     `rank` -- the host-side statement of rt_local_pixel_map: tiles of tile_size^2
-    in row-major order, tile t owned by rank t % world; inside a tile 8x8 pixel
-    blocks in row-major order, pixels row-major inside a block."""
+    in row-major order, dealt to the ranks in groups of `world`, the k-th group
+    turned by a hash of k (RtTileMap::tile_of in csrc/rt_internal.h); inside a
+    tile 8x8 pixel blocks in row-major order, pixels row-major inside a block.
+    Every rank has one tile of every group, so in the last group some ranks'
+    tile may lie beyond the image: all padding."""
     tiles_x = (width + tile_size - 1) // tile_size
     tiles_y = (height + tile_size - 1) // tile_size
     total = tiles_x * tiles_y
-    n_local = (total - rank + world - 1) // world if total > rank else 0
+    n_local = (total + world - 1) // world
     ts2 = tile_size * tile_size
     slot = np.arange(n_local * ts2, dtype=np.int64)
     k, within = slot // ts2, slot % ts2
-    t = k * world + rank
+    turn = _group_turn(k, world)
+    t = k * world + (rank + turn) % world
     tx, ty = t % tiles_x, t // tiles_x
     b, lane = within >> 6, within & 63
     bpr = tile_size >> 3

@@ -515,7 +515,11 @@ def test_shadow_rays_that_stop_at_their_first_hit_do_not_change_a_bit(core, non_
         assert (images[0][1][..., :3] == 1).all()
 
 
-def test_tiles_union_is_bit_identical_to_whole_frame(core):
+@pytest.mark.parametrize("world,tile", [(3, 32), (8, 8), (5, 64)])
+def test_tiles_union_is_bit_identical_to_whole_frame(core, world, tile):
+    """A share of the image queues its camera rays frame by frame, the whole image block by block, and every rank has
+    one tile of every group of `world` (5 ranks, 64x64 tiles: 12 tiles, the last group holds two -- three ranks end on a
+    tile beyond the image): the shares put together are the bits of the undivided render."""
     sc = scenes.cornell_box(200, 136, sphere_segments=16)     # not a multiple of the tile size
     seeds = scenes.frame_seeds(2, seed=6)
     core.upload(sc)
@@ -526,9 +530,9 @@ def test_tiles_union_is_bit_identical_to_whole_frame(core):
     whole = core.readback(wire.IMAGE_CONVERGED)
     union = np.zeros_like(whole)
     covered = np.zeros(whole.shape[:2], bool)
-    for rank in range(3):
+    for rank in range(world):
         p = sc.params.copy()
-        p.tileRank, p.tileCount, p.tileSize = rank, 3, 32
+        p.tileRank, p.tileCount, p.tileSize = rank, world, tile
         core.set_params(p)
         core.set_dirty()
         core.render_frames(seeds)

@@ -17,7 +17,7 @@ def test_local_pixel_map_matches_host_statement(core):
     sc = scenes.cornell_box(200, 136, sphere_segments=8)
     core.upload(sc)
     core.bvh_build()
-    for rank, world, ts in ((0, 1, 64), (1, 3, 32), (2, 3, 32), (7, 8, 64)):
+    for rank, world, ts in ((0, 1, 64), (1, 3, 32), (2, 3, 32), (7, 8, 64), (3, 8, 8), (4, 5, 64), (0, 5, 64)):
         p = sc.params.copy()
         p.tileRank, p.tileCount, p.tileSize = rank, world, ts
         core.set_params(p)

@@ -289,7 +289,7 @@ def test_tile_gatherer_places_by_a_precomputed_permutation():
             f = g.place().numpy()
             assert np.array_equal(f[..., 0].reshape(-1), np.arange(w * h, dtype=np.float32))
             ty, tx = np.mgrid[0:h, 0:w]
-            owner = ((ty // ts) * ((w + ts - 1) // ts) + tx // ts) % n
+            owner = rtdist.tile_owner((ty // ts) * ((w + ts - 1) // ts) + tx // ts, n)
             assert np.array_equal(f[..., 1], owner.astype(np.float32)) and (f[..., 2] == twice).all()
         with pytest.raises(RuntimeError):
             g.gather()
@@ -332,7 +332,7 @@ def _worker(rank, world, port, tmp):
         assert np.array_equal(f[..., 0].reshape(-1), np.arange(96 * 80, dtype=np.float32))
         tiles_x = 3
         ty, tx = np.mgrid[0:80, 0:96]
-        owner = ((ty // 32) * tiles_x + tx // 32) % world
+        owner = rtdist.tile_owner((ty // 32) * tiles_x + tx // 32, world)
         assert np.array_equal(f[..., 1], owner.astype(np.float32))
         open(os.path.join(tmp, "ok"), "w").write("ok")
     else:

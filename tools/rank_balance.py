@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracing_amd import native, scenes  # noqa: E402
 
 world = int(sys.argv[1])
-tile = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+tile = int(sys.argv[2]) if len(sys.argv) > 2 else (64 if world == 1 else 8)
 spp = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 sc = scenes.car_standin(1920, 1080)
 core = native.RtCore(0)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time one rank's share of the bench frame on one GPU: the tiles rank 0 of `world` would own.
-Usage: rank_share.py world [spp]"""
+Usage: rank_share.py world [spp]   (TILE: tile size, 8 for a share as in bench.py; RT_OPTS: rt_set_option pairs)"""
 import json
 import os
 import sys
@@ -14,7 +14,7 @@ sc = scenes.car_standin(1920, 1080)
 core = native.RtCore(0)
 core.upload(sc); core.bvh_build()
 p = sc.params.copy()
-p.tileRank, p.tileCount, p.tileSize = 0, world, int(os.environ.get("TILE", "64"))
+p.tileRank, p.tileCount, p.tileSize = 0, world, int(os.environ.get("TILE", "64" if world == 1 else "8"))
 core.set_params(p)
 for kv in filter(None, os.environ.get("RT_OPTS", "").split(",")):     # rt_set_option pairs, e.g. RT_OPTS=5=1
     k, v = kv.split("="); core.set_option(int(k), int(v))
