@@ -321,29 +321,29 @@ __global__ void k_pack_rays(const float *__restrict__ o3, const float *__restric
 template <uint32_t DOF_FLAG, bool CLEAR_RT>
 __global__ __launch_bounds__(Q_THREADS) void k_generate(RtTileMap tm, RtParams P, const float *__restrict__ seeds, uint32_t nFrames,
                                                          float4 *__restrict__ ray, float4 *__restrict__ pe,
-                                                         float4 *__restrict__ img, uint2 *__restrict__ rng, uint32_t *__restrict__ qcount, uint32_t frameMajor)
+                                                         float4 *__restrict__ img, uint2 *__restrict__ rng, uint32_t *__restrict__ qcount,
+                                                         uint32_t *__restrict__ qpos)
 {
     __shared__ uint32_t stage[Q_TILE];
     const uint32_t total = tm.nSlots * nFrames;
 #pragma unroll 1
     for (int it = 0; it < Q_ITEMS; ++it) {
-        // Thread q makes path g = frame * nSlots + slot with (8x8-pixel block, frame, lane) read off q in that
-        // order, so the queue holds a pixel block's rays of ALL frames in flight next to each other: the waves
-        // that walk them at about the same time fetch the same nodes and triangles (frame-major order meets a
-        // pixel block again only a whole frame of rays later).  nSlots is a multiple of 64.
-        // frameMajor: g = q instead, for a context that renders a share of the image's tiles, whose consecutive blocks
-        // lie apart in the image: there block order is the slower one (measured on an eighth of the 1080p bench image
-        // in 8x8 tiles, 64 frames: the camera rays' launch takes 3.0 .. 4.1 ms in block order, 1.8 ms in frame order).
+        // Thread q makes path q: the camera rays are queued frame by frame, a frame's pixel blocks in tile order (a wave
+        // of the walker holds one 8x8 block; nSlots is a multiple of 64).  The ShadowMap pass wants another order -- a
+        // pixel block's rays of all frames next to each other, k_sm_setup -- and finds a path's ray and hit through
+        // qpos[path] = the path's place in this queue (RT_INVALID: a padding slot, never queued).
         const uint32_t q = blockIdx.x * Q_TILE + it * Q_THREADS + threadIdx.x;
-        const uint32_t wave = q >> 6;
-        uint32_t frame = wave % nFrames, slot = (wave / nFrames) * 64u + (q & 63u);
-        if (frameMajor) slot = tm.local_slot(q, &frame);
-        const uint32_t g = q < total ? frame * tm.nSlots + slot : RT_INVALID;
+        uint32_t frame;
+        const uint32_t slot = tm.local_slot(q, &frame);
+        const uint32_t g = q < total ? q : RT_INVALID;
         uint32_t px = 0, py = 0;
         const bool active = q < total && tm.slot_to_pixel(slot, &px, &py);
         // padding slots of the image read 0.  A live CSMain path gets its radiance sum and its energy from the first shading
         // pass, which knows both start values (0 and 1) without reading them; a live ShadowMap pixel is written by its pass
-        if (q < total && !active) img[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (q < total && !active) {
+            img[g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            qpos[g] = RT_INVALID;
+        }
         stage[it * Q_THREADS + threadIdx.x] = active ? g : RT_INVALID;
     }
     // the ray of an active path is made once its place in the queue is known, and written there
@@ -360,6 +360,7 @@ __global__ __launch_bounds__(Q_THREADS) void k_generate(RtTileMap tm, RtParams P
         else d_camera_ray(P, uvx, uvy, o, d);
         ray_record_store(ray, at, o, d, g);
         rng[g] = make_uint2(r.state, __float_as_uint(r.seed));
+        qpos[g] = at;
     });
 }
 
@@ -517,23 +518,33 @@ __global__ __launch_bounds__(Q_THREADS) void k_shade(RtSceneView sv, RtBruteView
 // generate (primary ray, DoF-capable) -> traverse -> setup (hit point, disk
 // rotation) -> traverse 16 shadow rays per shaded pixel -> resolve.
 __global__ __launch_bounds__(Q_THREADS) void k_sm_setup(RtSceneView sv, RtTileMap tm, RtParams P, const float4 *__restrict__ ray,
-                                                   const uint32_t *__restrict__ qcount, const uint2 *__restrict__ rng,
+                                                   const uint2 *__restrict__ rng,
                                                    const RtHitRec *__restrict__ hitRec, float4 *__restrict__ rec, float4 *__restrict__ recQ,
                                                    float4 *__restrict__ shadowMap, uint32_t *__restrict__ smq,
                                                    uint32_t *__restrict__ smqCount, ShadowFrame frame, int skipUnshadowable,
-                                                   unsigned long long *__restrict__ shadowRayCounter)
+                                                   unsigned long long *__restrict__ shadowRayCounter, const uint32_t *__restrict__ qpos,
+                                                   uint32_t nFrames)
 {
     __shared__ uint32_t stage[Q_TILE];
-    const uint32_t n = *qcount;
-    if (blockIdx.x * Q_TILE >= n) return;
+    const uint32_t total = tm.nSlots * nFrames;
 #pragma unroll 1
     for (int it = 0; it < Q_ITEMS; ++it) {
-    const uint32_t i = blockIdx.x * Q_TILE + it * Q_THREADS + threadIdx.x;
+    // Thread j takes the path (8x8-pixel block, frame, lane) read off j in that order: the shadow queue holds a pixel
+    // block's rays of ALL frames in flight next to each other, and the waves that walk them at about the same time
+    // fetch the same nodes and triangles (frame order meets a pixel block again only a whole frame of rays later).
+    // The camera and bounce rays are the other way round: queued by pixel block they walk slower than queued by frame
+    // (1080p, 64 frames: all eight launches 23.0 against 21.9 ms, the shadow launch 48.7 against 49.2; both queues
+    // in their better order: 83.3 ms per image against 84.4 by block and 85.2 by frame; an eighth of the image in 8x8
+    // tiles: 12.6 against 14.4 and 13.0).
+    const uint32_t j = blockIdx.x * Q_TILE + it * Q_THREADS + threadIdx.x;
+    const uint32_t wave = j >> 6;
+    const uint32_t path = (wave % nFrames) * tm.nSlots + (wave / nFrames) * 64u + (j & 63u);
+    const uint32_t i = j < total ? qpos[path] : RT_INVALID;
     bool shaded = false, skipped = false;
     uint32_t slot = 0;
-    if (i < n) {
+    if (i != RT_INVALID) {
         const float4 r0 = ray[2 * (size_t)i], r1 = ray[2 * (size_t)i + 1];
-        slot = __float_as_uint(r1.z);
+        slot = path;
         const RtHitRec h = hitRec[i];
         if (h.leaf == RT_INVALID) {
             shadowMap[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
@@ -762,7 +773,7 @@ void rt_free_render(RtContext *ctx)
     void **ptrs[] = {(void **)&ctx->dRt, (void **)&ctx->dConv, (void **)&ctx->dShadowMap,
                      (void **)&ctx->dPe, (void **)&ctx->dRng, (void **)&ctx->dHit,
                      (void **)&ctx->dRay[0], (void **)&ctx->dRay[1], (void **)&ctx->dSmQueue, (void **)&ctx->dSmRec, (void **)&ctx->dSmRecQ,
-                     (void **)&ctx->dSmFlags, (void **)&ctx->dSeeds};
+                     (void **)&ctx->dSmFlags, (void **)&ctx->dSeeds, (void **)&ctx->dQPos};
     for (void **p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -782,7 +793,7 @@ static int alloc_batch(RtContext *ctx, uint32_t frames)
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     void **ptrs[] = {(void **)&ctx->dRt, (void **)&ctx->dShadowMap, (void **)&ctx->dPe,
                      (void **)&ctx->dRng, (void **)&ctx->dHit, (void **)&ctx->dRay[0], (void **)&ctx->dRay[1],
-                     (void **)&ctx->dSmQueue, (void **)&ctx->dSmRec, (void **)&ctx->dSmRecQ, (void **)&ctx->dSmFlags, (void **)&ctx->dSeeds};
+                     (void **)&ctx->dSmQueue, (void **)&ctx->dSmRec, (void **)&ctx->dSmRecQ, (void **)&ctx->dSmFlags, (void **)&ctx->dSeeds, (void **)&ctx->dQPos};
     for (void **p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -797,6 +808,7 @@ static int alloc_batch(RtContext *ctx, uint32_t frames)
     RT_HIP(ctx, hipMalloc((void **)&ctx->dRay[0], m * 2 * sizeof(float4)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dRay[1], m * 2 * sizeof(float4)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dSmQueue, m * sizeof(uint32_t)));
+    RT_HIP(ctx, hipMalloc((void **)&ctx->dQPos, m * sizeof(uint32_t)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dSmRec, m * 2 * sizeof(float4)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dSmRecQ, m * 2 * sizeof(float4)));
     RT_HIP(ctx, hipMalloc((void **)&ctx->dSmFlags, m * 16));
@@ -888,12 +900,14 @@ static bool shadow_shares_primary(const RtParams &P)
 
 static ShadowFrame shadow_frame(RtContext *ctx);
 
-static void launch_sm_setup(RtContext *ctx, const RtSceneView &sv, uint32_t total, const float4 *ray, const uint32_t *qcount)
+// (the primary rays and their hits are found through dQPos, which the k_generate launch of the same frames filled)
+static void launch_sm_setup(RtContext *ctx, const RtSceneView &sv, uint32_t frames, const float4 *ray)
 {
+    const uint32_t total = ctx->tile.nSlots * frames;
     rt_timer_begin(ctx, "k_sm_setup");
-    hipLaunchKernelGGL(k_sm_setup, dim3((total + Q_TILE - 1) / Q_TILE), dim3(Q_THREADS), 0, ctx->stream, sv, ctx->tile, ctx->params, ray, qcount,
+    hipLaunchKernelGGL(k_sm_setup, dim3((total + Q_TILE - 1) / Q_TILE), dim3(Q_THREADS), 0, ctx->stream, sv, ctx->tile, ctx->params, ray,
                        ctx->dRng, ctx->dHit, ctx->dSmRec, ctx->dSmRecQ, ctx->dShadowMap, ctx->dSmQueue, ctx->dQCount + CNT_SMQ,
-                       shadow_frame(ctx), ctx->optCasterBox ? 1 : 0, ctx->countersOn ? ctx->dStats + 37 : nullptr);
+                       shadow_frame(ctx), ctx->optCasterBox ? 1 : 0, ctx->countersOn ? ctx->dStats + 37 : nullptr, ctx->dQPos, frames);
     rt_timer_end(ctx);
 }
 
@@ -1122,10 +1136,6 @@ static int overlap_join(RtContext *ctx, const RtSceneView &sceneView, uint32_t t
     return rc ? rc : overlap_finish(ctx, sceneView, total);
 }
 
-// Order of the camera rays in their queue (k_generate): by frame for a share of the image, by pixel block for all of it
-// (1080p, 64 frames in flight: 84.4 ms by block, 85.2 by frame; an eighth of it in 8x8 tiles: 14.4 and 13.0).
-static uint32_t queue_frame_major(const RtContext *ctx) { return ctx->tile.count > 1 ? 1u : 0u; }
-
 // CSMain for `frames` frames of the current view (seeds already in dSeeds).
 // withShadowSetup: also prepare the ShadowMap pass from CSMain's own primary hits.
 // overlapAfter >= 0 (needs withShadowSetup): the shadow rays start after the extend launch of that bounce
@@ -1142,7 +1152,7 @@ static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup
     RT_HIP(ctx, hipMemsetAsync(ctx->dQCount, 0, CNT_WORDS * sizeof(uint32_t), st));
     rt_timer_begin(ctx, "k_generate");
     hipLaunchKernelGGL((k_generate<RT_FLAG_DOF_PRIMARY, true>), grid, blk, 0, st, ctx->tile, ctx->params, ctx->dSeeds, frames,
-                       ctx->dRay[0], ctx->dPe, ctx->dRt, ctx->dRng, ctx->dQCount, queue_frame_major(ctx));
+                       ctx->dRay[0], ctx->dPe, ctx->dRt, ctx->dRng, ctx->dQCount, ctx->dQPos);
     rt_timer_end(ctx);
     for (int b = 0; b < RT_MAX_BOUNCE; ++b) {
         float4 *qin = ctx->dRay[b & 1], *qout = ctx->dRay[(b + 1) & 1];
@@ -1156,7 +1166,7 @@ static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup
             rt_timer_end(ctx);
         } else if (b == 0 && ctx->optPacketPrimary) launch_traverse_packets(ctx, sv, src, ctx->dQCount + CNT_CURSOR(b), total, "k_extend");
         else launch_traverse(ctx, sv, src, ctx->dQCount + CNT_CURSOR(b), total, "k_extend");
-        if (b == 0 && withShadowSetup) launch_sm_setup(ctx, sv, total, qin, ctx->dQCount);   // before shade moves the rays on
+        if (b == 0 && withShadowSetup) launch_sm_setup(ctx, sv, frames, qin);   // before shade moves the rays on
         if (b == overlapAfter) {
             const int rc = overlap_fork(ctx, sv, total);
             if (rc) return rc;
@@ -1193,7 +1203,7 @@ static int shadowmap_frames(RtContext *ctx, uint32_t frames)
     RT_HIP(ctx, hipMemsetAsync(cnt + CNT_FETCH_SM0, 0, 2 * CNT_LINE * sizeof(uint32_t), st));    // both ShadowMap cursors
     rt_timer_begin(ctx, "k_sm_generate");
     hipLaunchKernelGGL((k_generate<RT_FLAG_DEPTH_OF_FIELD, false>), dim3((total + Q_TILE - 1) / Q_TILE), dim3(Q_THREADS), 0, st, ctx->tile, ctx->params,
-                       ctx->dSeeds, frames, ctx->dRay[0], ctx->dPe, ctx->dShadowMap, ctx->dRng, cnt + CNT_SMPRIM, queue_frame_major(ctx));
+                       ctx->dSeeds, frames, ctx->dRay[0], ctx->dPe, ctx->dShadowMap, ctx->dRng, cnt + CNT_SMPRIM, ctx->dQPos);
     rt_timer_end(ctx);
     QueueSrc prim;
     prim.ray = ctx->dRay[0];
@@ -1201,7 +1211,7 @@ static int shadowmap_frames(RtContext *ctx, uint32_t frames)
     prim.hit = ctx->dHit;
     if (ctx->optPacketPrimary) launch_traverse_packets(ctx, sv, prim, cnt + CNT_FETCH_SM0, total, "k_extend");
     else launch_traverse(ctx, rt_scene_view(ctx), prim, cnt + CNT_FETCH_SM0, total, "k_extend");
-    launch_sm_setup(ctx, sv, total, ctx->dRay[0], cnt + CNT_SMPRIM);
+    launch_sm_setup(ctx, sv, frames, ctx->dRay[0]);
     launch_shadow_rays(ctx, sv, total);
     RT_HIP(ctx, hipGetLastError());
     return RT_OK;
@@ -1233,18 +1243,18 @@ struct RtLaneScope {
     float4 *rt, *sm, *pe, *smRec, *smRecQ, *ray0, *ray1;
     uint2 *rng;
     RtHitRec *hit;
-    uint32_t *smq, *cnt;
+    uint32_t *smq, *cnt, *qpos;
     uint8_t *smFlags;
     float *seeds;
     uint32_t frameLane;
     RtLaneScope(RtContext *c, hipStream_t s, uint32_t firstFrame, uint32_t *counters, uint32_t area = 1, uint32_t frameLaneIndex = 0)
         : ctx(c), stream(c->stream), rt(c->dRt), sm(c->dShadowMap), pe(c->dPe), smRec(c->dSmRec), smRecQ(c->dSmRecQ), ray0(c->dRay[0]), ray1(c->dRay[1]), rng(c->dRng),
-          hit(c->dHit), smq(c->dSmQueue), cnt(c->dQCount), smFlags(c->dSmFlags), seeds(c->dSeeds), frameLane(frameLaneIndex)
+          hit(c->dHit), smq(c->dSmQueue), cnt(c->dQCount), qpos(c->dQPos), smFlags(c->dSmFlags), seeds(c->dSeeds), frameLane(frameLaneIndex)
     {
         const size_t off = (size_t)firstFrame * c->tile.nSlots;
         c->stream = s;
         c->dRt += off; c->dShadowMap += off; c->dPe += off; c->dRng += off; c->dHit += off;
-        c->dRay[0] += 2 * off; c->dRay[1] += 2 * off; c->dSmQueue += off; c->dSmRec += 2 * off; c->dSmRecQ += 2 * off; c->dSmFlags += 16 * off;
+        c->dRay[0] += 2 * off; c->dRay[1] += 2 * off; c->dSmQueue += off; c->dQPos += off; c->dSmRec += 2 * off; c->dSmRecQ += 2 * off; c->dSmFlags += 16 * off;
         c->dSeeds += firstFrame;
         c->dQCount = counters;
         c->spillArea = area;     // (two streams of one batch: area 1 -- the overlapped shadow launch, its other user, is off then)
@@ -1266,7 +1276,7 @@ struct RtLaneScope {
         c->scopeLane = 0;
         c->stream = stream;
         c->dRt = rt; c->dShadowMap = sm; c->dPe = pe; c->dSmRec = smRec; c->dSmRecQ = smRecQ; c->dRng = rng; c->dHit = hit;
-        c->dRay[0] = ray0; c->dRay[1] = ray1; c->dSmQueue = smq; c->dQCount = cnt; c->dSmFlags = smFlags; c->dSeeds = seeds;
+        c->dRay[0] = ray0; c->dRay[1] = ray1; c->dSmQueue = smq; c->dQPos = qpos; c->dQCount = cnt; c->dSmFlags = smFlags; c->dSeeds = seeds;
         c->spillArea = 0;
     }
 };

@@ -309,6 +309,7 @@ struct RtContext {
     RtHitRec *dHit = nullptr;
     uint32_t *dQCount = nullptr;          // 32-word counter block, owned by the context
     uint32_t *dSmQueue = nullptr;         // ShadowMap pass: shaded path slots
+    uint32_t *dQPos = nullptr;            // per path: its place in the camera rays' queue (RT_INVALID: a padding slot)
     float *dSeeds = nullptr;              // per-frame seeds of the batch in flight
     bool optPacketShadow = false, optPacketPrimary = false, optPacketTrace = false;
     bool optMaterialSort = true;
