@@ -506,7 +506,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_name,
-                       "parallelism": f"image tiles {tile_size}x{tile_size}, one of every {world} consecutive tiles to each of {world} GPU(s)"},
+                       "parallelism": ("the whole image on one GPU" if world == 1 else f"image tiles {tile_size}x{tile_size}, one of every {world} consecutive tiles to each of {world} GPUs")},
             "value_counts": "rays walked: the BVHRayTrace calls a traversal kernel took through the tree.  The reference makes more "
                             "calls for the same frames (rays_answered_per_step): the library answers the 16 soft-shadow rays of a "
                             "ShadowMap pixel that no shadow caster can reach without a walk",
