@@ -515,11 +515,12 @@ def test_shadow_rays_that_stop_at_their_first_hit_do_not_change_a_bit(core, non_
         assert (images[0][1][..., :3] == 1).all()
 
 
-@pytest.mark.parametrize("world,tile", [(3, 32), (8, 8), (5, 64)])
+@pytest.mark.parametrize("world,tile", [(3, 32), (8, 8), (5, 64), (16, 64)])
 def test_tiles_union_is_bit_identical_to_whole_frame(core, world, tile):
     """A share of the image queues its camera rays frame by frame, the whole image block by block, and every rank has
     one tile of every group of `world` (5 ranks, 64x64 tiles: 12 tiles, the last group holds two -- three ranks end on a
-    tile beyond the image): the shares put together are the bits of the undivided render."""
+    tile beyond the image; 16 ranks: four of them have nothing but such a tile): the shares put together are the bits of the
+    undivided render."""
     sc = scenes.cornell_box(200, 136, sphere_segments=16)     # not a multiple of the tile size
     seeds = scenes.frame_seeds(2, seed=6)
     core.upload(sc)
