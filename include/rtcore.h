@@ -148,8 +148,8 @@ typedef struct RtParams {
      * order turned from group to group by a hash of the group's number, so that
      * no rank's tiles form columns or diagonals of the image (which tile is a
      * rank's k-th: rt_local_pixel_map tells, per pixel slot).  Small tiles even
-     * the ranks' loads out: an eighth of the 1080p bench image takes 11.7 ..
-     * 14.5 ms from rank to rank in 64 x 64 tiles, 12.8 .. 13.0 ms in 8 x 8.  Pixel
+     * the ranks' loads out: the eight shares of the 1080p bench image differ by
+     * a fifth of their time in 64 x 64 tiles, by a fiftieth in 8 x 8.  Pixel
      * coordinates given to the RNG stay global, so the union of all ranks'
      * tiles is bit-identical to a single-GPU frame.  tileCount <= 1 = whole
      * frame.  tileSize: a multiple of 8, at most 1024; <= 0 = 64. */

@@ -766,7 +766,7 @@ RtSceneView rt_scene_view(RtContext *ctx)
 #define CNT_WORDS (24 * CNT_LINE)
 static_assert(RT_FRAME_LANES * CNT_WORDS <= RT_COUNTER_BLOCK_WORDS, "counter block too small");   // one per lane
 #define RT_MAX_BATCH 64u
-#define RT_BATCH_PATH_SLOTS (1u << 27)   // frames in flight are chosen so that a launch covers up to this many paths (220 B each: 29 GB)
+#define RT_BATCH_PATH_SLOTS (1u << 27)   // frames in flight are chosen so that a launch covers up to this many paths (224 B each: 30 GB)
 
 void rt_free_render(RtContext *ctx)
 {
