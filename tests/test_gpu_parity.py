@@ -975,3 +975,45 @@ def test_unusual_orders_of_the_per_frame_calls_with_frames_in_flight(core):
                 H.assert_bits_equal(a, b, f"{name}, RT_OPT_PIPELINE_FRAMES {lanes}")
     finally:
         core.set_option(wire.OPT_PIPELINE_FRAMES, 1)
+
+
+def test_a_share_of_the_image_through_the_per_frame_calls_with_frames_in_flight(core):
+    """One rank of three (8x8 tiles in hashed groups) drives its share frame by frame with four frames in flight, then
+    with the batch call: both give, on the rank's pixels, the bits of the undivided frame; everything else reads 0."""
+    sc = scenes.car_standin(200, 136, detail=0.1)
+    use_shadow = bool(sc.params.flags & wire.FLAG_MATTE_MASK)
+    seeds = scenes.frame_seeds(6, seed=71)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(sc.params)
+    core.set_dirty()
+    core.render_frames(seeds)
+    whole = [core.readback(w) for w in (wire.IMAGE_CONVERGED, wire.IMAGE_SHADOWMAP)]
+    p = sc.params.copy()
+    p.tileRank, p.tileCount, p.tileSize = 1, 3, 8
+    core.set_params(p)
+    pm = core.local_pixel_map()
+    mask = np.zeros(200 * 136, bool)
+    mask[pm[pm != 0xFFFFFFFF]] = True
+    mask = mask.reshape(136, 200)
+    assert 0.3 < mask.mean() < 0.37
+
+    def check(what):
+        for name, got, want in zip(("converged", "shadow map"), [core.readback(w) for w in (wire.IMAGE_CONVERGED, wire.IMAGE_SHADOWMAP)], whole):
+            if name == "shadow map" and not use_shadow:
+                continue
+            H.assert_bits_equal(got[mask], want[mask], f"{name}, {what}")
+            assert (got[~mask] == 0).all(), f"{name}, {what}: pixels of other ranks"
+
+    core.set_dirty()
+    core.render_frames(seeds)
+    check("batch call")
+    core.set_dirty()
+    for k, seed in enumerate(seeds):
+        p.seed = float(seed)
+        core.set_params(p)
+        core.dispatch()
+        if use_shadow:
+            core.dispatch_shadowmap()
+        core.accumulate(k, use_shadow)
+    check("per-frame calls, four frames in flight")
