@@ -161,7 +161,8 @@ public static class RtCoreNative
     public const int RT_OPT_PACKET_SHADOW = 0, RT_OPT_PACKET_PRIMARY = 1, RT_OPT_PACKET_TRACE = 2, RT_OPT_BATCH_FRAMES = 3,
                      RT_OPT_MATERIAL_SORT = 4, RT_OPT_TWO_STREAMS = 5, RT_OPT_OVERLAP_SHADOW = 6, RT_OPT_OVERLAP_AFTER = 7,
                      RT_OPT_OVERLAP_CUS = 8, RT_OPT_FIRST_HIT_SHADOW = 9, RT_OPT_CASTER_BOX = 10, RT_OPT_EAGER_SHADOWMAP = 11,
-                     RT_OPT_PRUNE_BY_DISTANCE = 12, RT_OPT_SHARE_LONG_WALKS = 13, RT_OPT_WIDE_NODES = 14, RT_OPT_PIPELINE_FRAMES = 15;
+                     RT_OPT_PRUNE_BY_DISTANCE = 12, RT_OPT_SHARE_LONG_WALKS = 13, RT_OPT_WIDE_NODES = 14, RT_OPT_PIPELINE_FRAMES = 15,
+                     RT_OPT_CHAIN_BOUNCES = 16;
     [DllImport(Lib)] public static extern int rt_enable_counters(IntPtr ctx, int enable);
     [DllImport(Lib)] public static extern int rt_enable_kernel_timing(IntPtr ctx, int enable);
     [DllImport(Lib)] public static extern int rt_reset_stats(IntPtr ctx);

@@ -770,6 +770,10 @@ int rt_set_option(RtContext *ctx, int option, int value)
         if (value < 0 || value > RT_FRAME_LANES) return rt_fail(ctx, RT_E_INVALID, "RT_OPT_PIPELINE_FRAMES must be 0 .. %d", RT_FRAME_LANES);
         ctx->optPipelineFrames = value == 0 ? 1 : (value == 1 ? RT_FRAME_LANES : value);
         return RT_OK;
+    case RT_OPT_CHAIN_BOUNCES:
+        if (value < 0 || value >= RT_MAX_BOUNCE) return rt_fail(ctx, RT_E_INVALID, "RT_OPT_CHAIN_BOUNCES must be 0 .. %d", RT_MAX_BOUNCE - 1);
+        ctx->optChainBounces = value;
+        return RT_OK;
     case RT_OPT_PACKET_SHADOW: ctx->optPacketShadow = value != 0; return RT_OK;
     case RT_OPT_PACKET_PRIMARY: ctx->optPacketPrimary = value != 0; return RT_OK;
     case RT_OPT_PACKET_TRACE: ctx->optPacketTrace = value != 0; return RT_OK;

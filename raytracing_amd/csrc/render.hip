@@ -514,6 +514,138 @@ __global__ __launch_bounds__(Q_THREADS) void k_shade(RtSceneView sv, RtBruteView
     });
 }
 
+// ------------------------------------------------------------------ the later bounces of a few paths in one launch
+// A bounce launch lasts as long as its longest ray, and from the third bounce on a frame or two hold so few paths that
+// the launches are nothing but that: five of them, 0.2 ms each, with a shading launch in between.  Here a wave takes 64
+// paths of the queue of bounce `firstBounce` and brings them to their ends by itself -- walk (the walker, drawing from
+// a list of the wave's own live paths in LDS), shade (k_shade's arithmetic for one path, its state kept in registers),
+// walk again -- so a path waits for the longest ray among 64 per bounce, not among all, and nothing waits for a launch.
+// Paths are independent and carry their own random stream: which wave shades them when changes no value.
+struct WaveSrc {             // the live paths of one wave, in LDS
+    static constexpr bool FIRST_HIT_MAY_DECIDE = false;
+    __device__ __forceinline__ bool first_hit_decides(const rt_f3, const rt_f3, const rt_f3) const { return false; }
+    float *rays;               // component c of the path on lane e: rays[c * 64 + e], c = 0..5 (origin, direction)
+    uint32_t *hits;            // word c of its hit record: hits[c * 64 + e]
+    const uint32_t *list;      // list[j]: the lane of the j-th live path
+    uint32_t n;
+    __device__ __forceinline__ uint32_t count() const { return n; }
+    __device__ __forceinline__ void load(uint32_t j, rt_f3 &o, rt_f3 &d) const
+    {
+        const uint32_t e = list[j];
+        o = rt_mk3(rays[e], rays[64 + e], rays[128 + e]);
+        d = rt_mk3(rays[192 + e], rays[256 + e], rays[320 + e]);
+    }
+    __device__ __forceinline__ void store(uint32_t j, const RtHitRec &h) const
+    {
+        const uint32_t e = list[j];
+        hits[e] = __float_as_uint(h.t);
+        hits[64 + e] = __float_as_uint(h.u);
+        hits[128 + e] = __float_as_uint(h.v);
+        hits[192 + e] = h.leaf;
+    }
+};
+#define CHAIN_WAVE_WORDS (11 * 64)    // 6 ray components, 4 hit words, the list
+
+__global__ __launch_bounds__(TRV_THREADS, 2) void k_traverse_chain(RtSceneView sv, RtTileMap tm, RtParams P, int firstBounce,
+                                                                      const float4 *__restrict__ rayIn, const uint32_t *__restrict__ countIn,
+                                                                      uint32_t *__restrict__ cursor, const float4 *__restrict__ pe,
+                                                                      float4 *__restrict__ rt, const uint2 *__restrict__ rng)
+{
+    __shared__ uint32_t lds[TRV_LDS_WORDS];
+    __shared__ uint32_t own[(TRV_THREADS / 64) * CHAIN_WAVE_WORDS];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t *mine = own + (threadIdx.x >> 6) * CHAIN_WAVE_WORDS;
+    WaveSrc src;
+    src.rays = (float *)mine;
+    src.hits = mine + 6 * 64;
+    src.list = mine + 10 * 64;
+    uint32_t *list = mine + 10 * 64;
+    const uint32_t n = *countIn;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(cursor, 64u);         // (fewer paths to a wave, 8 .. 32, change nothing: a chain is as long as its path's rays)
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= n) break;
+        const uint32_t i = base + lane;
+        bool alive = i < n;
+        DRay ray;
+        ray.origin = ray.direction = ray.energy = rt_splat3(0.0f);
+        rt_f3 col = rt_splat3(0.0f);
+        uint32_t slot = 0;
+        rt_rng rs;
+        rs.state = 0; rs.seed = 0.0f; rs.px = rs.py = 0.0f;
+        if (alive) {
+            const float4 r0 = rayIn[2 * (size_t)i], r1 = rayIn[2 * (size_t)i + 1];
+            slot = __float_as_uint(r1.z);
+            const float4 e4 = pe[slot], c4 = rt[slot];
+            const uint2 s2 = rng[slot];
+            uint32_t px, py, frameOfSlot;
+            tm.slot_to_pixel(tm.local_slot(slot, &frameOfSlot), &px, &py);   // global pixel coordinates feed Rand()
+            ray.origin = rt_mk3(r0.x, r0.y, r0.z);
+            ray.direction = rt_mk3(r0.w, r1.x, r1.y);
+            ray.energy = rt_mk3(e4.x, e4.y, e4.z);
+            col = rt_mk3(c4.x, c4.y, c4.z);
+            rs.state = s2.x;
+            rs.seed = __uint_as_float(s2.y);
+            rs.px = (float)px;
+            rs.py = (float)py;
+        }
+        const bool mineToWrite = alive;
+#pragma unroll 1
+        for (int bounce = firstBounce; bounce < RT_MAX_BOUNCE; ++bounce) {
+            const unsigned long long live = __ballot(alive);
+            if (live == 0ull) break;
+            if (alive) {
+                list[__popcll(live & ((1ull << lane) - 1ull))] = lane;
+                src.rays[lane] = ray.origin.x; src.rays[64 + lane] = ray.origin.y; src.rays[128 + lane] = ray.origin.z;
+                src.rays[192 + lane] = ray.direction.x; src.rays[256 + lane] = ray.direction.y; src.rays[320 + lane] = ray.direction.z;
+            }
+            src.n = (uint32_t)__popcll(live);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            traverse_rays<false>(sv, src, nullptr, lds);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (alive) {
+                // (k_shade's arithmetic for one path; the two are held to the same bits by the tests that compare the
+                //  per-frame calls with the batch call)
+                RtHitRec h;
+                h.t = __uint_as_float(src.hits[lane]); h.u = __uint_as_float(src.hits[64 + lane]); h.v = __uint_as_float(src.hits[128 + lane]);
+                h.leaf = src.hits[192 + lane];
+                alive = false;
+                if (h.leaf == RT_INVALID) {
+                    const rt_f3 sky = d_shade_miss(sv, P, ray.direction);
+                    col = rt_add3(col, rt_mul3(ray.energy, sky));
+                } else {
+                    DHit hit;
+                    int castShadow;
+                    load_hit(sv, h, ray.origin, ray.direction, hit, castShadow);
+                    if (hit.materialType == 2) {
+                        const rt_f3 add = rt_mul3(ray.energy, hit.emissionColor);
+                        for (int k = bounce; k < RT_MAX_BOUNCE; ++k) col = rt_add3(col, add);
+                    } else if (hit.materialType == 4) {
+                        ray.origin = rt_sub3(hit.position, rt_scale3(hit.normal, RT_NORMAL_BIAS));
+                        col = rt_add3(col, rt_mul3(ray.energy, rt_splat3(0.0f)));
+                        alive = rt_any3(ray.energy);
+                    } else {
+                        DShadeCtx c;
+                        c.sv = &sv;
+                        c.P = &P;
+                        c.rng = rs;
+                        const rt_f3 energyBefore = ray.energy;
+                        const rt_f3 f = d_function_bsdf(c, hit, ray);
+                        ray.energy = rt_mul3(ray.energy, f);
+                        col = rt_add3(col, rt_mul3(energyBefore, rt_splat3(0.0f)));
+                        rs = c.rng;
+                        alive = rt_any3(ray.energy);
+                    }
+                }
+            }
+        }
+        if (mineToWrite) rt[slot] = make_float4(col.x, col.y, col.z, 0.0f);
+    }
+}
+
 // ------------------------------------------------------------------ ShadowMap pass (RayTracing.compute:96-131)
 // generate (primary ray, DoF-capable) -> traverse -> setup (hit point, disk
 // rotation) -> traverse 16 shadow rays per shaded pixel -> resolve.
@@ -1154,8 +1286,21 @@ static int dispatch_frames(RtContext *ctx, uint32_t frames, bool withShadowSetup
     hipLaunchKernelGGL((k_generate<RT_FLAG_DOF_PRIMARY, true>), grid, blk, 0, st, ctx->tile, ctx->params, ctx->dSeeds, frames,
                        ctx->dRay[0], ctx->dPe, ctx->dRt, ctx->dRng, ctx->dQCount, ctx->dQPos);
     rt_timer_end(ctx);
+    // (RT_OPT_CHAIN_BOUNCES) few paths in flight: the bounces from this one on are one launch, k_traverse_chain
+    const int chainFrom = (!brute && !ctx->countersOn && ctx->optChainBounces >= 1 && ctx->optChainBounces > overlapAfter && total <= (1u << 23))
+                              ? ctx->optChainBounces : -1;
     for (int b = 0; b < RT_MAX_BOUNCE; ++b) {
         float4 *qin = ctx->dRay[b & 1], *qout = ctx->dRay[(b + 1) & 1];
+        if (b == chainFrom) {
+            uint32_t blocks = (uint32_t)ctx->numCU * 3u;        // (three blocks of its 150 registers a lane fit a unit)
+            const uint32_t need = (total + TRV_THREADS - 1) / TRV_THREADS;
+            if (need < blocks) blocks = need ? need : 1;
+            rt_timer_begin(ctx, "k_chain");
+            hipLaunchKernelGGL(k_traverse_chain, dim3(blocks), dim3(TRV_THREADS), 0, st, sv, ctx->tile, ctx->params, b, qin, ctx->dQCount + CNT_Q(b),
+                               ctx->dQCount + CNT_CURSOR(b), ctx->dPe, ctx->dRt, ctx->dRng);
+            rt_timer_end(ctx);
+            break;
+        }
         QueueSrc src;
         src.ray = qin;
         src.qcount = ctx->dQCount + CNT_Q(b);

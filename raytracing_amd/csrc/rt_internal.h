@@ -246,6 +246,7 @@ struct RtContext {
     hipEvent_t evLaneIdle[RT_FRAME_LANES] = {};
     bool accumulatedPending[RT_FRAME_LANES] = {};
     bool laneBusy[RT_FRAME_LANES] = {};               // the lane's stream may hold work that lane 0's stream has not waited for
+    int optChainBounces = 3;                          // RT_OPT_CHAIN_BOUNCES: first bounce of the one-launch chain, 0 = off
     int optPipelineFrames = RT_FRAME_LANES;           // lanes in use (1: the per-frame calls go down one stream)
     uint32_t frameLane = 0, nextLane = 0; // the lane of the frame rt_dispatch last started, and of the next one
     uint32_t lastFoldLane = 0;            // the lane whose rt_accumulate came last

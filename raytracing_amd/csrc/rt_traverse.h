@@ -244,7 +244,7 @@ __device__ __forceinline__ float lane_value(float x, uint32_t from) { return __u
 
 struct RayFeed {
     uint32_t *cursor;
-    uint32_t total, next, end, chunk, waves2;    // wave-uniform
+    uint32_t total, next, end, chunk, waves2, own;    // wave-uniform (own: the cursor of a wave that draws alone, cursor == nullptr)
     bool lastChunk, exhausted;
     __device__ __forceinline__ uint32_t chunk_for(uint32_t remaining) const
     {
@@ -259,6 +259,7 @@ struct RayFeed {
         cursor = c;
         total = wave_uniform(n);
         next = end = 0;
+        own = 0;
         waves2 = gridDim.x * (blockDim.x >> 6) * TRV_CHUNK_SHARE;
         chunk = chunk_for(total);
         lastChunk = false;
@@ -270,9 +271,15 @@ struct RayFeed {
     {
         if (next == end && !lastChunk) {
             const uint32_t take = chunk ? chunk : want;
-            uint32_t base = 0;
-            if ((threadIdx.x & 63u) == 0) base = atomicAdd(cursor, take);
-            base = wave_uniform(base);                         // lane 0's
+            uint32_t base;
+            if (cursor) {
+                base = 0;
+                if ((threadIdx.x & 63u) == 0) base = atomicAdd(cursor, take);
+                base = wave_uniform(base);                     // lane 0's
+            } else {                                           // rays that are this wave's alone: nothing to share a cursor with
+                base = own;
+                own += take;
+            }
             next = base < total ? base : total;
             end = total - next < take ? total : next + take;
             lastChunk = end == total;

@@ -91,7 +91,7 @@ class RtStats(C.Structure):
 OPT_PACKET_SHADOW, OPT_PACKET_PRIMARY, OPT_PACKET_TRACE, OPT_BATCH_FRAMES, OPT_MATERIAL_SORT, OPT_TWO_STREAMS = 0, 1, 2, 3, 4, 5
 OPT_OVERLAP_SHADOW, OPT_OVERLAP_AFTER, OPT_OVERLAP_CUS = 6, 7, 8
 OPT_FIRST_HIT_SHADOW, OPT_CASTER_BOX, OPT_EAGER_SHADOWMAP, OPT_PRUNE_BY_DISTANCE = 9, 10, 11, 12
-OPT_SHARE_LONG_WALKS, OPT_WIDE_NODES, OPT_PIPELINE_FRAMES = 13, 14, 15
+OPT_SHARE_LONG_WALKS, OPT_WIDE_NODES, OPT_PIPELINE_FRAMES, OPT_CHAIN_BOUNCES = 13, 14, 15, 16
 
 
 class RtBloomParams(C.Structure):

@@ -1017,3 +1017,51 @@ def test_a_share_of_the_image_through_the_per_frame_calls_with_frames_in_flight(
             core.dispatch_shadowmap()
         core.accumulate(k, use_shadow)
     check("per-frame calls, four frames in flight")
+
+
+@pytest.mark.parametrize("scene", ["cornell", "pbr grid", "car with ShadowMap pass"])
+def test_later_bounces_in_one_launch_do_not_change_a_bit(core, scene):
+    """RT_OPT_CHAIN_BOUNCES: the bounces from the k-th on walked and shaded by one launch (a wave brings 64 paths to
+    their ends) against every bounce a launch of its own -- batch call and per-frame calls, k = 1 .. 7."""
+    if scene == "cornell":
+        sc = scenes.cornell_box(256, 160, sphere_segments=24)
+    elif scene == "pbr grid":
+        sc = scenes.pbr_sphere_grid(256, 160, sphere_segments=16)
+    else:
+        sc = scenes.car_standin(256, 160, detail=0.1)
+    use_shadow = bool(sc.params.flags & wire.FLAG_MATTE_MASK)
+    seeds = scenes.frame_seeds(3, seed=17)
+    core.upload(sc)
+    core.bvh_build()
+    core.set_params(sc.params)
+
+    def images():
+        return [core.readback(w) for w in (wire.IMAGE_RT, wire.IMAGE_CONVERGED)]
+
+    try:
+        core.set_option(wire.OPT_CHAIN_BOUNCES, 0)
+        core.set_dirty()
+        core.render_frames(seeds)
+        want = images()
+        assert np.isfinite(want[1]).all() and want[1][..., :3].max() > 0
+        for k in (3, 1, 2, 5, 7):
+            core.set_option(wire.OPT_CHAIN_BOUNCES, k)
+            core.set_dirty()
+            core.render_frames(seeds)
+            for name, a, b in zip(("rt", "converged"), images(), want):
+                H.assert_bits_equal(a, b, f"{name}, batch call, RT_OPT_CHAIN_BOUNCES {k}")
+            core.set_dirty()
+            p = sc.params.copy()
+            for j, seed in enumerate(seeds):
+                p.seed = float(seed)
+                core.set_params(p)
+                core.dispatch()
+                if use_shadow:
+                    core.dispatch_shadowmap()
+                core.accumulate(j, use_shadow)
+            for name, a, b in zip(("rt", "converged"), images(), want):
+                H.assert_bits_equal(a, b, f"{name}, per-frame calls, RT_OPT_CHAIN_BOUNCES {k}")
+        with pytest.raises(Exception):
+            core.set_option(wire.OPT_CHAIN_BOUNCES, 8)
+    finally:
+        core.set_option(wire.OPT_CHAIN_BOUNCES, 3)

@@ -58,9 +58,15 @@ def check_function(lines):
             header = None
             for j in range(i, max(i - 60, -1), -1):               # nearest loop header above the test
                 m = re.match(r"^(\.LBB\d+_\d+):", lines[j])
-                if m and j + 1 < len(lines) and "Loop Header" in lines[j + 1] + lines[min(j + 2, len(lines) - 1)]:
-                    header = m.group(1)
-                    break
+                if m:
+                    # the label's comment runs over the lines that follow it, one per enclosing loop
+                    note, k = lines[j], j + 1
+                    while k < len(lines) and lines[k].lstrip().startswith(";") and not re.match(r"^\S", lines[k]):
+                        note += lines[k]
+                        k += 1
+                    if "Loop Header" in note:
+                        header = m.group(1)
+                        break
             if header is None:
                 bad.append("phase test at line %d has no loop header above it" % i)
                 continue
