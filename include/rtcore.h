@@ -230,7 +230,10 @@ int rt_trace_primitives(RtContext *ctx, const float *origins, const float *direc
 
 /* --------------------------------------------------------------- BVH build */
 /* MeshData.Calculate + ComputeBufferSorter.Sort + DistributeMortonCode +
- * BVHConstructor.ConstructTree/ConstructBVH (BVH.cs:128-170). */
+ * BVHConstructor.ConstructTree/ConstructBVH (BVH.cs:128-170).
+ * A scene whose vertices move is uploaded and built again (BVH.cs rebuilds on a changed transform): while the triangle
+ * count stays what it was, rt_scene_upload and rt_bvh_build reuse their device buffers and the build its scratch (kept
+ * between builds while it is 1 GiB at most), so such a build costs its kernels and nothing else. */
 int rt_bvh_build(RtContext *ctx);
 
 /* Debug readbacks in the reference wire structs, what BVH.OnDrawGizmos reads

@@ -95,14 +95,15 @@ static int use_device(RtContext *ctx)
         if (eagerRc_) return eagerRc_;                           \
     } while (0)
 
+// had: how many elements *dst was made for (it is kept when that is `count`)
 template <typename T>
-static int upload(RtContext *ctx, T **dst, const T *src, size_t count)
+static int upload(RtContext *ctx, T **dst, const T *src, size_t count, size_t had = ~(size_t)0)
 {
-    if (*dst) {
+    if (*dst && had != count) {
         (void)hipFree(*dst);
         *dst = nullptr;
     }
-    RT_HIP(ctx, hipMalloc((void **)dst, (count ? count : 1) * sizeof(T)));
+    if (!*dst) RT_HIP(ctx, hipMalloc((void **)dst, (count ? count : 1) * sizeof(T)));
     if (count) RT_HIP(ctx, hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
     return RT_OK;
 }
@@ -197,6 +198,8 @@ int rt_destroy(RtContext *ctx)
             if (st) (void)hipStreamSynchronize(st);
     rt_timer_resolve(ctx);
     for (hipEvent_t e : ctx->eventPool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->buildEvents)
+        if (e) (void)hipEventDestroy(e);
     rt_free_build(ctx);
     rt_free_render(ctx);
     rt_free_post(ctx);
@@ -274,13 +277,14 @@ int rt_scene_upload(RtContext *ctx, const RtMeshVertex *vertices, uint32_t n_ver
     ctx->nonCasterBox = nc;
     ctx->casterBox = ca;
     int rc;
-    if ((rc = upload(ctx, &ctx->dVerts, vertices, n_vertices))) return rc;
-    if ((rc = upload(ctx, &ctx->dIdx, indices, n_indices))) return rc;
-    if ((rc = upload(ctx, &ctx->dMatIdx, material_index, n_triangles))) return rc;
-    if ((rc = upload(ctx, &ctx->dShadow, shadow_index_xy, 2 * (size_t)n_triangles))) return rc;
+    if ((rc = upload(ctx, &ctx->dVerts, vertices, n_vertices, (size_t)ctx->nVerts))) return rc;
+    if ((rc = upload(ctx, &ctx->dIdx, indices, n_indices, 3 * (size_t)ctx->N))) return rc;
+    if ((rc = upload(ctx, &ctx->dMatIdx, material_index, n_triangles, (size_t)ctx->N))) return rc;
+    if ((rc = upload(ctx, &ctx->dShadow, shadow_index_xy, 2 * (size_t)n_triangles, 2 * (size_t)ctx->N))) return rc;
+    if (n_triangles != ctx->N) rt_free_build(ctx);     // (as many triangles as before: the next build reuses the buffers)
+    ctx->built = false;
     ctx->nVerts = n_vertices;
     ctx->N = n_triangles;
-    rt_free_build(ctx);
     ctx->sampleCount = 0;
     return RT_OK;
 }

@@ -855,8 +855,52 @@ void rt_free_build(RtContext *ctx)
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
+    for (auto &b : ctx->buildScratch)
+        if (b.first) (void)hipFree(b.first);
+    ctx->buildScratch.clear();
+    ctx->buildBuffersN = 0;
     ctx->built = false;
 }
+
+// A build's scratch: asked for in the same order with the same sizes by every build of the same triangle count, so the
+// k-th request of a build takes the k-th buffer the last one left if its size is the same.  What a build leaves is kept
+// while it is no more than RT_BUILD_SCRATCH_KEEP bytes; more than that is freed when the build ends, however it ends.
+struct RtBuildScratchPool {
+    RtContext *ctx;
+    size_t next = 0;
+    explicit RtBuildScratchPool(RtContext *c) : ctx(c) {}
+    RtBuildScratchPool(const RtBuildScratchPool &) = delete;
+    RtBuildScratchPool &operator=(const RtBuildScratchPool &) = delete;
+    template <typename T>
+    hipError_t alloc(T **p, size_t count)
+    {
+        const size_t bytes = (count ? count : 1) * sizeof(T);
+        auto &pool = ctx->buildScratch;
+        if (next == pool.size()) pool.emplace_back(nullptr, 0);
+        auto &slot = pool[next];
+        if (slot.first == nullptr || slot.second != bytes) {
+            if (slot.first) (void)hipFree(slot.first);
+            slot.first = nullptr;
+            slot.second = 0;
+            const hipError_t e = hipMalloc(&slot.first, bytes);
+            if (e != hipSuccess) return e;
+            slot.second = bytes;
+        }
+        *p = (T *)slot.first;
+        next += 1;
+        return hipSuccess;
+    }
+    ~RtBuildScratchPool()
+    {
+        size_t total = 0;
+        for (const auto &b : ctx->buildScratch) total += b.second;
+        if (total <= RT_BUILD_SCRATCH_KEEP) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto &b : ctx->buildScratch)
+            if (b.first) (void)hipFree(b.first);
+        ctx->buildScratch.clear();
+    }
+};
 
 template <typename T>
 static hipError_t dalloc(T **p, size_t count)
@@ -1007,7 +1051,9 @@ static int build_tree_from_keys(RtContext *ctx, BuildScratch &sc, uint32_t N, ui
 int rt_build_impl(RtContext *ctx)
 {
     const uint32_t N = ctx->N;
-    rt_free_build(ctx);
+    const bool reuse = N != 0 && ctx->buildBuffersN == N;       // the last build's buffers fit: as many triangles
+    if (!reuse) rt_free_build(ctx);
+    ctx->built = false;
     memset(&ctx->rootBox, 0, sizeof ctx->rootBox);
     ctx->smallEdgeProduct = ctx->smallEdgeSum = 0.0f;
     if (N >= RT_REF_INDEX) return rt_fail(ctx, RT_E_INVALID, "BVH build: at most 2^30 - 2 triangles");
@@ -1026,26 +1072,29 @@ int rt_build_impl(RtContext *ctx)
     RtAABB *wBvhData = nullptr;
     BuildPlan *plan = nullptr;
     float4 *wLeafBox = nullptr;
-    RtArena arena(ctx->stream);             // scratch and events go when the build ends, however it ends
+    RtBuildScratchPool arena(ctx);
 
     RT_HIP(ctx, arena.alloc(&plan, 1));
     RT_HIP(ctx, arena.alloc(&wLeafBox, (size_t)N * 2));
-    RT_HIP(ctx, dalloc(&ctx->dTriAABB, (size_t)N));
-    RT_HIP(ctx, dalloc(&ctx->dMortonUnsorted, (size_t)N));
-    RT_HIP(ctx, dalloc(&ctx->dMortonSortedRaw, (size_t)N));
-    RT_HIP(ctx, dalloc(&ctx->dMorton, (size_t)N));
-    RT_HIP(ctx, dalloc(&ctx->dSortedIdx, (size_t)N));
-    RT_HIP(ctx, dalloc(&ctx->dLeft, (size_t)NI));
-    RT_HIP(ctx, dalloc(&ctx->dRight, (size_t)NI));
-    RT_HIP(ctx, dalloc(&ctx->dParent, (size_t)NI));
-    RT_HIP(ctx, dalloc(&ctx->dLeafParent, (size_t)N));
-    RT_HIP(ctx, dalloc(&ctx->dBvhData, (size_t)NI));
-    RT_HIP(ctx, dalloc(&ctx->dNodes, (size_t)NI));
-    RT_HIP(ctx, dalloc(&ctx->dQNodes, (size_t)NI));
-    RT_HIP(ctx, dalloc(&ctx->dWNodes, (size_t)NI));
-    RT_HIP(ctx, dalloc(&ctx->dLeafTri, (size_t)N));
-    RT_HIP(ctx, dalloc(&ctx->dLeafShade, (size_t)N));
-    RT_HIP(ctx, dalloc(&ctx->dLeafRank, (size_t)N));
+    if (!reuse) {
+        RT_HIP(ctx, dalloc(&ctx->dTriAABB, (size_t)N));
+        RT_HIP(ctx, dalloc(&ctx->dMortonUnsorted, (size_t)N));
+        RT_HIP(ctx, dalloc(&ctx->dMortonSortedRaw, (size_t)N));
+        RT_HIP(ctx, dalloc(&ctx->dMorton, (size_t)N));
+        RT_HIP(ctx, dalloc(&ctx->dSortedIdx, (size_t)N));
+        RT_HIP(ctx, dalloc(&ctx->dLeft, (size_t)NI));
+        RT_HIP(ctx, dalloc(&ctx->dRight, (size_t)NI));
+        RT_HIP(ctx, dalloc(&ctx->dParent, (size_t)NI));
+        RT_HIP(ctx, dalloc(&ctx->dLeafParent, (size_t)N));
+        RT_HIP(ctx, dalloc(&ctx->dBvhData, (size_t)NI));
+        RT_HIP(ctx, dalloc(&ctx->dNodes, (size_t)NI));
+        RT_HIP(ctx, dalloc(&ctx->dQNodes, (size_t)NI));
+        RT_HIP(ctx, dalloc(&ctx->dWNodes, (size_t)NI));
+        RT_HIP(ctx, dalloc(&ctx->dLeafTri, (size_t)N));
+        RT_HIP(ctx, dalloc(&ctx->dLeafShade, (size_t)N));
+        RT_HIP(ctx, dalloc(&ctx->dLeafRank, (size_t)N));
+        ctx->buildBuffersN = N;
+    }
     RT_HIP(ctx, arena.alloc(&sc.keysB, (size_t)N));
     RT_HIP(ctx, arena.alloc(&sc.valsB, (size_t)N));
     RT_HIP(ctx, arena.alloc(&sc.blockHist, (size_t)sc.histLen));
@@ -1066,9 +1115,9 @@ int rt_build_impl(RtContext *ctx)
     RT_HIP(ctx, arena.alloc(&wBvhData, (size_t)NI));
 
     hipStream_t st = ctx->stream;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    RT_HIP(ctx, arena.event(&e0));
-    RT_HIP(ctx, arena.event(&e1));
+    for (hipEvent_t &e : ctx->buildEvents)
+        if (!e) RT_HIP(ctx, hipEventCreate(&e));
+    const hipEvent_t e0 = ctx->buildEvents[0], e1 = ctx->buildEvents[1];
     RT_HIP(ctx, hipEventRecord(e0, st));
     RT_HIP(ctx, hipMemsetAsync(sc.counts, 0, PASS_COUNT_WORDS * sizeof(uint32_t), st));
 

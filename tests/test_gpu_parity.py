@@ -1065,3 +1065,34 @@ def test_later_bounces_in_one_launch_do_not_change_a_bit(core, scene):
             core.set_option(wire.OPT_CHAIN_BOUNCES, 8)
     finally:
         core.set_option(wire.OPT_CHAIN_BOUNCES, 3)
+
+
+def test_a_build_after_a_build_of_as_many_triangles_reuses_its_buffers_and_keeps_the_bits(core, oracle):
+    """A scene whose vertices move keeps its triangle count: the library then builds into the buffers and the scratch of
+    the build before (no allocation in between).  Moved vertices, the same scene twice, another count and back again:
+    every build's arrays, the two-level tree and first hits against the checker's."""
+    import copy
+    import torch
+    keys = ("morton_unsorted", "morton_sorted_raw", "morton", "sorted_index", "tri_aabb", "triangles", "internal", "leaves", "bvh_data")
+    base = scenes.triangle_soup(20000, seed=5)
+    moved = copy.deepcopy(base)
+    rs = np.random.Generator(np.random.PCG64(3))
+    moved.vertices["position"] = (moved.vertices["position"] * np.float32(0.7) + rs.normal(0, 2.0, moved.vertices["position"].shape)).astype(np.float32)
+    other = scenes.triangle_soup(7001, seed=8)
+    o, d = H.random_rays(20000, 3, -110, 110)
+    free = []
+    for step, sc in enumerate((base, moved, moved, base, other, base)):
+        orc = oracle.Oracle(sc).build()
+        want = orc.readback_bvh()
+        core.upload(sc)
+        core.bvh_build()
+        free.append(torch.cuda.mem_get_info()[0])
+        got = core.readback_bvh()
+        for key in keys:
+            H.assert_bits_equal(got[key], want[key], f"build {step}: {key}")
+        hits, ref = core.trace_rays(o, d), orc.trace(o, d)
+        H.assert_bits_equal(hits["triangle"], ref["triangle"], f"build {step}: first-hit triangle")
+        H.assert_bits_equal(hits["t"], ref["t"], f"build {step}: hit distance")
+    # builds 1 .. 3 have as many triangles as the build before them: device memory stays as it was (the first build's figure
+    # predates what the first trace and readback keep)
+    assert free[1] == free[2] == free[3], free
