@@ -424,8 +424,13 @@ int rt_save_rgb24(RtContext *ctx, int which, uint8_t *dst_rgb);
  * (packets pay off only where the 16 rays stay inside the same few leaves; on finely
  *  tessellated scenes the one-ray-per-lane walker is about twice as fast)
  *   RT_OPT_MATERIAL_SORT   1 (default): a shading block groups its 2048 paths by material class first
- *   RT_OPT_TWO_STREAMS     0 (default): 1 = the frames in flight go down two HIP streams, half each
- *                          (measured 3 % slower: the walkers already fill the chip)
+ *   RT_OPT_TWO_STREAMS     how many streams the frames of a batch (rt_render_frames) go down.  -1 (default): the library
+ *                          chooses -- two frame lanes (each half of the frames with a stream, counter block, masked
+ *                          streams and spill areas of its own, so that one half's launch ends overlap the other half's
+ *                          work) for a batch of 8 M to 20 M paths, i.e. a share of the image (an eighth of the 1080p bench
+ *                          image: 12.7 -> 12.1 ms per 64 frames), one stream otherwise (the whole image loses 4 % to the
+ *                          split: the walkers already fill the chip).  0: one stream; 2 .. 4: that many frame lanes; 1: two
+ *                          plain streams, the overlap of RT_OPT_OVERLAP_SHADOW off.  Same bits however the frames are split.
  *   RT_OPT_BATCH_FRAMES    1..64 frames rt_render_frames keeps in flight; 0 (default): as many as give
  *                          up to 128 M paths per launch (64 for a whole 1080p frame, 16 for a 4K frame; 220 bytes of
  *                          device memory per path, halved until it fits)

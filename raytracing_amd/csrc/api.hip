@@ -783,7 +783,7 @@ int rt_set_option(RtContext *ctx, int option, int value)
     case RT_OPT_PACKET_TRACE: ctx->optPacketTrace = value != 0; return RT_OK;
     case RT_OPT_MATERIAL_SORT: ctx->optMaterialSort = value != 0; return RT_OK;
     case RT_OPT_TWO_STREAMS:
-        if (value < 0 || value > 2) return rt_fail(ctx, RT_E_INVALID, "RT_OPT_TWO_STREAMS must be 0, 1 or 2");
+        if (value < -1 || value > RT_FRAME_LANES) return rt_fail(ctx, RT_E_INVALID, "RT_OPT_TWO_STREAMS must be -1 .. %d", RT_FRAME_LANES);
         ctx->optTwoStreams = value;
         return RT_OK;
     case RT_OPT_CASTER_BOX: ctx->optCasterBox = value != 0; return RT_OK;

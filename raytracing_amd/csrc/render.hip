@@ -1436,7 +1436,7 @@ struct RtLaneScope {
 // built in frame order with the same operations -- same bits as one frame after the other.
 static bool lanes_active(RtContext *ctx)
 {
-    return ctx->optPipelineFrames >= 2 && !ctx->countersOn && !ctx->timingOn && !ctx->optTwoStreams && ctx->stream2 &&
+    return ctx->optPipelineFrames >= 2 && !ctx->countersOn && !ctx->timingOn && ctx->optTwoStreams <= 0 && ctx->stream2 &&
            ctx->batchCap >= (uint32_t)ctx->optPipelineFrames &&
            !(ctx->params.flags & RT_FLAG_BRUTE_FORCE);
 }
@@ -1584,6 +1584,22 @@ static int render_lane(RtContext *ctx, uint32_t frames, bool matte, bool shared)
     return rc;
 }
 
+// RT_OPT_TWO_STREAMS for a batch of f frames: 0 one stream, 1 two plain streams, 2 .. RT_FRAME_LANES that many frame lanes.
+// Left to the library (-1): two lanes for a batch of 8 M to 20 M paths -- a share of the image -- whose launches' ends
+// are worth filling with the other half's work (64 frames of a twelfth / an eighth of the 1080p bench image: 9.4 -> 8.7 /
+// 12.7 -> 12.1 ms; a sixth and a sixteenth: no difference; a fifth 18.7 -> 19.3, a quarter 22.7 -> 23.4, the whole image
+// 83.3 -> 86.5: there the halves only take units from each other; a thirty-second 4.3 -> 4.4).  Three and four lanes
+// lose to two (an eighth: 12.8 and 12.6).
+static int two_streams_mode(RtContext *ctx, uint32_t f)
+{
+    int mode = ctx->optTwoStreams;
+    if (mode < 0)
+        mode = (f >= 2 && (size_t)ctx->tile.nSlots * f <= ((size_t)20 << 20) && (size_t)ctx->tile.nSlots * f > ((size_t)1 << 23) &&
+                !ctx->countersOn && !ctx->timingOn && !(ctx->params.flags & RT_FLAG_BRUTE_FORCE)) ? 2 : 0;
+    if (mode == 0 || f < 2 || !ctx->stream2) return 0;
+    return mode > RT_FRAME_LANES ? RT_FRAME_LANES : mode;
+}
+
 // n x CustomRender, `batch` frames in flight at a time.  With RT_OPT_TWO_STREAMS the frames of a batch go
 // down two streams (first half / second half) so that one half's launch tails overlap the other half's work.
 int rt_render_frames_impl(RtContext *ctx, const float *seeds, uint32_t nFrames)
@@ -1601,23 +1617,31 @@ int rt_render_frames_impl(RtContext *ctx, const float *seeds, uint32_t nFrames)
     for (uint32_t base = 0; base < nFrames; base += batch) {
         const uint32_t f = nFrames - base < batch ? nFrames - base : batch;
         if ((rc = upload_seeds(ctx, seeds + base, f))) return rc;
-        const uint32_t fA = (ctx->optTwoStreams && f >= 2 && ctx->stream2) ? (f + 1) / 2 : f, fB = f - fA;
-        if (fB) {
-            // the second stream starts after the seeds are up (and, by stream order, after the last batch was folded in)
-            RT_HIP(ctx, hipEventRecord(ctx->evLaneIdle[1], ctx->stream));
-            RT_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->evLaneIdle[1], 0));
+        // parts: how many streams the batch goes down (1 plain).  Part k >= 1 gets frames of its own and either lane k's
+        // resources -- stream, counter block, masked streams, events, spill areas (RT_OPT_TWO_STREAMS 2 .. 4, and the
+        // automatic choice) -- or, with value 1, just a second stream
+        const int mode = two_streams_mode(ctx, f);
+        const uint32_t parts = mode <= 0 ? 1u : (mode == 1 ? 2u : (uint32_t)mode);
+        uint32_t first[RT_FRAME_LANES + 1];
+        for (uint32_t k = 0; k <= parts; ++k) first[k] = (uint32_t)(((uint64_t)f * k + parts - 1) / parts);   // part 0 is the largest
+        for (uint32_t k = 1; k < parts; ++k) {
+            const uint32_t fk = first[k + 1] - first[k];
+            if (!fk) continue;
+            // the part's stream starts after the seeds are up (and, by stream order, after the last batch was folded in)
+            RT_HIP(ctx, hipEventRecord(ctx->evLaneIdle[k], ctx->stream));
+            RT_HIP(ctx, hipStreamWaitEvent(ctx->laneStream[k], ctx->evLaneIdle[k], 0));
             {
-                // (2: a frame lane of its own -- masked streams, events, spill areas -- so that its shadow rays overlap its bounces too)
-                const bool ownLane = ctx->optTwoStreams == 2;
-                RtLaneScope lane(ctx, ctx->stream2, fA, ctx->dQCount + CNT_WORDS, ownLane ? 2u : 1u, ownLane ? 1u : 0u);
-                rc = render_lane(ctx, fB, matte, shared);
+                const bool ownLane = mode >= 2;
+                RtLaneScope lane(ctx, ctx->laneStream[k], first[k], ctx->dQCount + k * CNT_WORDS, ownLane ? 2u * k : 1u, ownLane ? k : 0u);
+                rc = render_lane(ctx, fk, matte, shared);
             }
             if (rc) return rc;
         }
-        if ((rc = render_lane(ctx, fA, matte, shared))) return rc;
-        if (fB) {
-            RT_HIP(ctx, hipEventRecord(ctx->evLaneIdle[1], ctx->stream2));
-            RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evLaneIdle[1], 0));
+        if ((rc = render_lane(ctx, first[1], matte, shared))) return rc;
+        for (uint32_t k = 1; k < parts; ++k) {
+            if (first[k + 1] == first[k]) continue;
+            RT_HIP(ctx, hipEventRecord(ctx->evLaneIdle[k], ctx->laneStream[k]));
+            RT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evLaneIdle[k], 0));
         }
         ctx->lastFrame = f - 1;
         if ((rc = accumulate_frames(ctx, f, ctx->sampleCount, matte ? 1 : 0, 0))) return rc;

@@ -320,7 +320,7 @@ struct RtContext {
     float *dSeeds = nullptr;              // per-frame seeds of the batch in flight
     bool optPacketShadow = false, optPacketPrimary = false, optPacketTrace = false;
     bool optMaterialSort = true;
-    int optTwoStreams = 0;                // RT_OPT_TWO_STREAMS: 1 = two plain streams, 2 = two frame lanes (each with its overlapped shadow rays)
+    int optTwoStreams = -1;               // RT_OPT_TWO_STREAMS: -1 = chosen per batch, 0 = one stream, 1 = two plain streams, 2 .. 4 = that many frame lanes (each with its overlapped shadow rays)
     float4 *dNonCasters = nullptr;        // leafTri-layout records of the non-casting triangles while they are at most RT_NONCASTER_LIST
     uint32_t nNonCasters = 0;
     RtAABB nonCasterBox = {{0, 0, 0}, 0, {0, 0, 0}, 0};   // round the triangles whose castShadow flag is not set (rt_scene_upload)

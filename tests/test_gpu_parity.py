@@ -355,6 +355,7 @@ def test_packet_walkers_do_not_change_a_bit(core):
         core.render_frames(seeds)
         images.append((core.readback(wire.IMAGE_CONVERGED), core.readback(wire.IMAGE_SHADOWMAP)))
     core.set_option(wire.OPT_MATERIAL_SORT, 1)
+    core.set_option(wire.OPT_TWO_STREAMS, -1)
     H.assert_bits_equal(images[0][0], images[1][0], "converged image, options on vs off")
     H.assert_bits_equal(images[0][1], images[1][1], "shadow map, packets on vs off")
     assert (images[0][1][..., 0] < 1).any()
@@ -1005,9 +1006,12 @@ def test_a_share_of_the_image_through_the_per_frame_calls_with_frames_in_flight(
             H.assert_bits_equal(got[mask], want[mask], f"{name}, {what}")
             assert (got[~mask] == 0).all(), f"{name}, {what}: pixels of other ranks"
 
-    core.set_dirty()
-    core.render_frames(seeds)
-    check("batch call")
+    for lanes in (-1, 0, 1, 2, 3, 4):                  # the frames of the batch down one stream, two, or two to four frame lanes
+        core.set_option(wire.OPT_TWO_STREAMS, lanes)
+        core.set_dirty()
+        core.render_frames(seeds)
+        check(f"batch call, RT_OPT_TWO_STREAMS {lanes}")
+    core.set_option(wire.OPT_TWO_STREAMS, -1)
     core.set_dirty()
     for k, seed in enumerate(seeds):
         p.seed = float(seed)

@@ -383,6 +383,33 @@ def test_car_1080p_execution_options_do_not_change_a_bit(core):
     assert (images[0][1][..., 0] < 1).any()
 
 
+def test_an_eighth_of_the_bench_image_down_two_frame_lanes(core):
+    """A rank's share of the bench workload at full size -- 8x8 tiles in hashed groups, 48 frames, 12.4 M paths: the size
+    at which the library sends the halves of a batch down two frame lanes by itself (RT_OPT_TWO_STREAMS -1) -- against
+    one stream and against three lanes."""
+    sc = scenes.car_standin(1920, 1080)
+    seeds = scenes.frame_seeds(48, seed=5)
+    core.upload(sc)
+    core.bvh_build()
+    p = sc.params.copy()
+    p.tileRank, p.tileCount, p.tileSize = 5, 8, 8
+    core.set_params(p)
+    images = {}
+    try:
+        for lanes in (0, -1, 3):
+            core.set_option(wire.OPT_TWO_STREAMS, lanes)
+            core.set_dirty()
+            core.render_frames(seeds)
+            images[lanes] = [core.readback(w) for w in (wire.IMAGE_CONVERGED, wire.IMAGE_SHADOWMAP, wire.IMAGE_RT)]
+    finally:
+        core.set_option(wire.OPT_TWO_STREAMS, -1)
+        core.set_params(sc.params)
+    assert (images[0][0][..., :3] > 0).mean() > 0.05
+    for lanes in (-1, 3):
+        for k, what in enumerate(("converged image", "shadow map of the last frame", "last frame")):
+            H.assert_bits_equal(images[lanes][k], images[0][k], f"{what}, RT_OPT_TWO_STREAMS {lanes}")
+
+
 @pytest.mark.parametrize("scene,image,median_max,within8_min", [
     ("chapter6_3", "cornellbox", 4.0, 0.80),       # MIS, one area light, glass / mirror / clear-coat objects, teapot + round boxes
     ("chapter6_4", "mis", 4.0, 0.88),              # MIS, 20 sphere lights over five plates of rising smoothness
