@@ -290,8 +290,13 @@ int rt_scene_upload(RtContext *ctx, const RtMeshVertex *vertices, uint32_t n_ver
     };
     {
         std::vector<std::thread> threads;
-        for (uint32_t k = 1; k < nThreads; ++k) threads.emplace_back(work, k);
+        uint32_t started = 1;                // parts [started, nThreads) are done here if no thread can be had for them
+        try {
+            for (; started < nThreads; ++started) threads.emplace_back(work, started);
+        } catch (...) {
+        }
         work(0);
+        for (uint32_t k = started; k < nThreads; ++k) work(k);
         for (std::thread &th : threads) th.join();
     }
     for (const Part &part : parts)
